@@ -1,0 +1,185 @@
+/*
+ * rtamd.h -- C ABI of the MI355X (gfx950) render pass for the Flyscene ray tracer.
+ *
+ * The reference renderer has no plugin or FFI boundary: Flyscene::raytraceScene()
+ * (src/flyscene.cpp:381-459) reads the members of one C++ object and fans out over std::thread.
+ * This header is the boundary a maintainer binds instead.  It is cut where the reference
+ * spawns and joins its worker threads (src/flyscene.cpp:413-435): everything tracePixels /
+ * traceRay read crosses it as plain arrays, and the image comes back in the layout of
+ * `pixel_data[y][x]` (src/flyscene.cpp:399-403,830).
+ *
+ * Conventions: every function returns RTAMD_OK (0) or an error code; the text of the last error
+ * of the calling thread is returned by rtamd_last_error().  Input arrays are copied; the caller
+ * keeps ownership of everything it passes.  A scene lives on the HIP device that is current when
+ * it is created; calls on one scene must not overlap.  All arithmetic is binary32 as in the
+ * reference (Eigen::Vector3f).
+ */
+#ifndef RTAMD_H
+#define RTAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTAMD_OK 0
+#define RTAMD_ERR_INVALID 1   /* bad argument (null pointer, index out of range, size <= 0)   */
+#define RTAMD_ERR_HIP 2       /* a HIP runtime call failed                                      */
+#define RTAMD_ERR_LIMIT 3     /* scene or image exceeds a documented limit                     */
+#define RTAMD_ERR_NO_DEVICE 4 /* no usable gfx950 device                                        */
+
+/* Face-id plane values besides face indices. */
+#define RTAMD_FACE_SPHERE (-1) /* src/flyscene.cpp:721 */
+#define RTAMD_FACE_MISS (-2)
+
+typedef struct rtamd_scene rtamd_scene;
+
+/* Tucano::Material::Mtl getters read on the path (materials/mtl.hpp:118-121). */
+typedef struct {
+    float ka[3];
+    float kd[3];
+    float ks[3];
+    float shininess;
+} rtamd_material;
+
+/* struct Sphere, src/defs.h:22-25. */
+typedef struct {
+    float center[3];
+    float radius;
+} rtamd_sphere;
+
+/* struct PrecomputedData (src/defs.h:7-20) plus what shadeOffFace/getLightIntensity read beside
+ * it: materials (src/flyscene.hpp:181), lights (src/flyscene.hpp:163) and spheres (:166). */
+typedef struct {
+    const float *vertices;             /* num_vertices*3, world space  (PrecomputedData::vertices)  */
+    const float *normals;              /* num_vertices*3, unit          (PrecomputedData::normals)   */
+    int32_t num_vertices;
+    const int32_t *face_vertex_ids;    /* num_faces*3                   (faceVertexIds)              */
+    const float *face_normals;         /* num_faces*3, unit             (faceNormals)                */
+    const float *face_origin_distance; /* num_faces                     (faceOriginDistance)         */
+    const int32_t *face_material_ids;  /* num_faces, -1 = none          (faceMaterialIds)            */
+    int32_t num_faces;
+    const rtamd_material *materials;
+    int32_t num_materials;
+    const float *light_positions;      /* num_lights*3                                               */
+    const float *light_colors;         /* num_lights*3 (carried; the reference never applies it)     */
+    int32_t num_lights;
+    const float *light_samples;        /* num_lights*samples_per_light*3 (PrecomputedData::lights)   */
+    int32_t samples_per_light;
+    const rtamd_sphere *spheres;
+    int32_t num_spheres;
+} rtamd_scene_desc;
+
+typedef struct {
+    int32_t max_leaf_faces; /* 1..15; 0 = default (4)                                              */
+    int32_t sah_bins;       /* 4..64; 0 = default (16)                                             */
+    int32_t reserved[6];
+} rtamd_build_params;
+
+/* What tracePixels/screenToWorld read from Tucano::Camera (camera.hpp:84,118-121,158-181). */
+typedef struct {
+    float origin[3];    /* getCenter()                                                           */
+    float inv_view[12]; /* inverseViewMatrix, row-major 3x4 = [linear | translation]             */
+    float viewport[4];  /* (x, y, width, height)                                                 */
+    float aspect_ratio; /* as given to setPerspectiveMatrix (src/flyscene.cpp:35)                */
+    float fovy;         /* degrees                                                               */
+} rtamd_camera;
+
+#define RTAMD_FLAG_COUNT_WORK 1u /* also count box tests / triangle tests (slower kernels)        */
+#define RTAMD_FLAG_TIME_KERNELS 2u /* bracket every launch with HIP events on the render stream   */
+
+/* The compile-time macros of src/flyscene.hpp:22-41 and the literals of src/flyscene.cpp as
+ * run-time fields, plus the row-tile partition used for multi-GPU rendering. */
+typedef struct {
+    int32_t width, height;    /* full image; must equal the viewport size (src/flyscene.cpp:394)   */
+    int32_t ssaa_level;       /* SSAALEVEL                                                         */
+    int32_t max_reflections;  /* MAXREFLECTIONS                                                    */
+    float reflect_threshold;  /* 0.25, src/flyscene.cpp:631                                        */
+    float bounce_offset;      /* 0.01, src/flyscene.cpp:636                                        */
+    float t_epsilon;          /* 1e-5, src/flyscene.cpp:707,760                                    */
+    float background[3];      /* 0.4,  src/flyscene.cpp:653-658                                    */
+    float background_deep[3]; /* 0.0,  src/flyscene.cpp:661-665                                    */
+    /* Row-tile partition: the image is cut into tiles of `row_tile` rows; tile k belongs to part
+     * k % num_parts.  A render call produces only the rows of `part`, packed top to bottom.
+     * (row_tile, 1, 0) renders the whole image.  The reference's analogue is the row interleave
+     * of its threads, src/flyscene.cpp:809. */
+    int32_t row_tile, num_parts, part;
+    uint32_t flags;
+    int32_t reserved[4];
+} rtamd_render_params;
+
+typedef struct {
+    uint64_t rays_primary; /* one per pixel sub-sample                                            */
+    uint64_t rays_shadow;  /* num_lights*samples_per_light per hit (src/flyscene.cpp:880-887)     */
+    uint64_t rays_bounce;  /* reflection rays (src/flyscene.cpp:636)                              */
+    uint64_t hits;         /* closest-hit queries that found a surface                            */
+    /* RTAMD_FLAG_COUNT_WORK only: */
+    uint64_t box_tests;    /* ray/AABB slab tests                                                 */
+    uint64_t tri_plane;    /* plane-distance evaluations                                          */
+    uint64_t tri_edge;     /* faces that reached the edge tests                                   */
+    /* RTAMD_FLAG_TIME_KERNELS only (milliseconds, summed over launches): */
+    float ms_trace;
+    float ms_shade;
+    float ms_total;
+    int32_t launches_trace;
+    int32_t launches_shade;
+    int32_t reserved[3];
+} rtamd_stats;
+
+typedef struct {
+    int32_t num_faces;        /* faces given                                                      */
+    int32_t num_device_faces; /* faces in the device BVH (zero-area faces are left out)           */
+    int32_t num_nodes;        /* 64-byte inner nodes                                              */
+    int32_t num_leaves;
+    int32_t depth;
+    int32_t device;           /* HIP device ordinal                                               */
+    uint64_t device_bytes;    /* scene data resident in HBM                                       */
+    float build_ms;           /* host BVH build                                                   */
+    float upload_ms;
+} rtamd_scene_info;
+
+const char *rtamd_last_error(void);
+
+/* Fill the defaults of the reference: Flycamera::reset + Flyscene::initialize(w, h)
+ * (utils/flycamera.hpp:76-86,166-191; src/flyscene.cpp:35-36) and the macros above. */
+void rtamd_camera_default(rtamd_camera *cam, int32_t width, int32_t height);
+void rtamd_render_params_default(rtamd_render_params *p, int32_t width, int32_t height);
+
+/* Replaces the tail of Flyscene::initialize (src/flyscene.cpp:116-134): takes the flattened scene,
+ * builds the 64-byte-node BVH that stands in for boundingBox::splitBox (src/boundingBox.h:69-194)
+ * and uploads everything to the current HIP device. */
+int rtamd_scene_create(const rtamd_scene_desc *desc, const rtamd_build_params *build, rtamd_scene **out);
+int rtamd_scene_destroy(rtamd_scene *scene);
+int rtamd_scene_get_info(const rtamd_scene *scene, rtamd_scene_info *info);
+
+/* Number of image rows part `p->part` renders, and the image row of local row `local_row`. */
+int32_t rtamd_local_rows(const rtamd_render_params *p);
+int32_t rtamd_global_row(const rtamd_render_params *p, int32_t local_row);
+
+/* Replaces spawn..join of Flyscene::raytraceScene (src/flyscene.cpp:413-435) together with
+ * tracePixels/traceRay/intersects/getLightIntensity/shadeOffFace below it.  Blocking.  Host
+ * buffers: rgb = local_rows*width*3 floats, row 0 = top, i.e. pixel_data[y][x] (:399-403,830);
+ * face_id (may be NULL) = local_rows*width ints: primary hit face, RTAMD_FACE_SPHERE or
+ * RTAMD_FACE_MISS; stats may be NULL. */
+int rtamd_render(rtamd_scene *scene, const rtamd_camera *cam, const rtamd_render_params *p, float *rgb,
+                 int32_t *face_id, rtamd_stats *stats);
+
+/* Same work, enqueued on `hip_stream` (a hipStream_t; NULL = default stream) without any host
+ * synchronisation; outputs are DEVICE pointers on the scene's device (face_id, t_hit may be NULL;
+ * t_hit = local_rows*width floats, primary hit distance, 0 on a miss).  After the stream has
+ * been synchronised, rtamd_render_stats() returns the counters of the most recent call. */
+int rtamd_render_device(rtamd_scene *scene, const rtamd_camera *cam, const rtamd_render_params *p, float *rgb_dev,
+                        int32_t *face_id_dev, float *t_hit_dev, void *hip_stream);
+int rtamd_render_stats(rtamd_scene *scene, rtamd_stats *stats);
+
+/* Interleave the packed rows of `num_parts` parts (as gathered on one device, part-major) back
+ * into image order.  src_dev = concatenation over parts of local_rows(part)*width*channels
+ * elements of 4 bytes; dst_dev = height*width*channels.  Enqueued on hip_stream. */
+int rtamd_assemble_rows(const rtamd_render_params *p, const void *src_dev, void *dst_dev, int32_t channels,
+                        void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

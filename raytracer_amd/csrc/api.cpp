@@ -1,0 +1,489 @@
+// C ABI of the render pass (include/rtamd.h): scene upload, frame orchestration, statistics.
+//
+// A frame is a fixed sequence of launches on one stream with no host round trip:
+//   memset(counters); for each SSAA pass, for depth 0..D: trace(depth), shade(depth); [scale]
+// which is the iterative form of Flyscene::traceRay's recursion (src/flyscene.cpp:581-667): the
+// colour C = local + ks*LI*C_next is accumulated front to back with a running throughput.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rtamd.h"
+#include "bvh.hpp"
+#include "device_types.h"
+#include "kernels.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+using namespace rtamd;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(RTAMD_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct TimedLaunch {
+    hipEvent_t start, stop;
+    int kind; // 0 trace, 1 shade, 2 other
+};
+
+} // namespace
+
+struct rtamd_scene {
+    int device = -1;
+    void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_materials = nullptr;
+    void *d_light_pos = nullptr, *d_samples = nullptr, *d_spheres = nullptr;
+    DeviceScene ds{};
+    Workspace ws{};
+    void *ws_block = nullptr;
+    rtamd_scene_info info{};
+    std::vector<rtamd_material> materials;
+    std::vector<int32_t> face_material;
+    // staging for the host-buffer entry point
+    float *d_rgb = nullptr;
+    int32_t *d_face = nullptr;
+    size_t staging_pixels = 0;
+    // bookkeeping of the most recent frame
+    bool have_frame = false;
+    rtamd_render_params last{};
+    int last_stages = 0, last_depths = 0;
+    uint64_t last_primary = 0;
+    hipStream_t last_stream = nullptr;
+    std::vector<TimedLaunch> events;
+    size_t events_used = 0;
+    hipEvent_t frame_start = nullptr, frame_stop = nullptr;
+};
+
+namespace {
+
+template <class T>
+int upload(void **dst, const std::vector<T> &src, uint64_t *bytes) {
+    const size_t n = src.size() * sizeof(T);
+    HIP_TRY(hipMalloc(dst, n ? n : 64));
+    if (n) HIP_TRY(hipMemcpy(*dst, src.data(), n, hipMemcpyHostToDevice));
+    *bytes += n;
+    return RTAMD_OK;
+}
+
+int ensure_workspace(rtamd_scene *s, size_t pixels) {
+    if (s->ws_block && (size_t)s->ws.capacity >= pixels) return RTAMD_OK;
+    if (pixels > (size_t)0x7fffffff / 4) return fail(RTAMD_ERR_LIMIT, "image part of %zu pixels exceeds the 2^29 pixel limit", pixels);
+    if (s->ws_block) {
+        HIP_TRY(hipFree(s->ws_block));
+        s->ws_block = nullptr;
+    }
+    // capacity rounded up so that every plane starts 256-byte aligned
+    const size_t cap = (pixels + 63) & ~(size_t)63;
+    const size_t planes = 2 /*slot, tri*/ + 3 /*hit point*/ + 20 /*two queues*/;
+    const size_t head = 4096; // stage counters + work counters
+    const size_t total = head + planes * cap * 4;
+    HIP_TRY(hipMalloc(&s->ws_block, total));
+    char *base = (char *)s->ws_block;
+    s->ws.stage = (StageCounters *)base;
+    s->ws.work = (WorkCounters *)(base + 2048);
+    static_assert(sizeof(StageCounters) * kMaxStages <= 2048, "counter block too small");
+    char *p = base + head;
+    s->ws.hit_slot = (int32_t *)p, p += cap * 4;
+    s->ws.hit_tri = (int32_t *)p, p += cap * 4;
+    s->ws.hit_p = (float *)p, p += 3 * cap * 4;
+    s->ws.queue[0] = (float *)p, p += 10 * cap * 4;
+    s->ws.queue[1] = (float *)p, p += 10 * cap * 4;
+    s->ws.capacity = (int32_t)cap;
+    return RTAMD_OK;
+}
+
+int check_params(const rtamd_scene *s, const rtamd_camera *cam, const rtamd_render_params *p) {
+    if (!s || !cam || !p) return fail(RTAMD_ERR_INVALID, "null scene, camera or params");
+    if (p->width <= 0 || p->height <= 0) return fail(RTAMD_ERR_INVALID, "image size %dx%d", p->width, p->height);
+    if (p->ssaa_level < 1 || p->ssaa_level > 8) return fail(RTAMD_ERR_INVALID, "ssaa_level %d outside 1..8", p->ssaa_level);
+    if (p->max_reflections < 0) return fail(RTAMD_ERR_INVALID, "max_reflections %d < 0", p->max_reflections);
+    if (p->row_tile < 1 || p->num_parts < 1 || p->part < 0 || p->part >= p->num_parts)
+        return fail(RTAMD_ERR_INVALID, "row partition (tile %d, parts %d, part %d)", p->row_tile, p->num_parts, p->part);
+    if (!(cam->viewport[2] > 0) || !(cam->viewport[3] > 0)) return fail(RTAMD_ERR_INVALID, "empty viewport");
+    return RTAMD_OK;
+}
+
+bool any_reflective(const rtamd_scene *s, float threshold) {
+    for (const rtamd_material &m : s->materials)
+        if (m.ks[0] > threshold || m.ks[1] > threshold || m.ks[2] > threshold) return true;
+    return false;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rtamd_last_error(void) { return g_error.c_str(); }
+
+void rtamd_camera_default(rtamd_camera *cam, int32_t width, int32_t height) {
+    if (!cam) return;
+    std::memset(cam, 0, sizeof *cam);
+    // Flycamera::reset: view = Translate(0, 0, -2)  ->  centre (0, 0, 2), inverse view = Translate(0, 0, 2)
+    cam->origin[2] = 2.0f;
+    cam->inv_view[0] = cam->inv_view[5] = cam->inv_view[10] = 1.0f;
+    cam->inv_view[11] = 2.0f;
+    cam->viewport[2] = (float)width;
+    cam->viewport[3] = (float)height;
+    cam->aspect_ratio = (float)width / (float)height;
+    cam->fovy = 60.0f;
+}
+
+void rtamd_render_params_default(rtamd_render_params *p, int32_t width, int32_t height) {
+    if (!p) return;
+    std::memset(p, 0, sizeof *p);
+    p->width = width, p->height = height;
+    p->ssaa_level = 1;
+    p->max_reflections = 5;
+    p->reflect_threshold = 0.25f;
+    p->bounce_offset = 0.01f;
+    p->t_epsilon = 0.00001f;
+    p->background[0] = p->background[1] = p->background[2] = (float)0.4;
+    p->row_tile = 16, p->num_parts = 1, p->part = 0;
+}
+
+int32_t rtamd_local_rows(const rtamd_render_params *p) {
+    if (!p || p->row_tile < 1 || p->num_parts < 1 || p->part < 0 || p->part >= p->num_parts || p->height <= 0) return 0;
+    const int ntiles = (p->height + p->row_tile - 1) / p->row_tile;
+    if (p->part >= ntiles) return 0;
+    const int tcount = (ntiles - p->part + p->num_parts - 1) / p->num_parts;
+    int rows = tcount * p->row_tile;
+    const int last_tile = p->part + (tcount - 1) * p->num_parts;
+    if ((last_tile + 1) * p->row_tile > p->height) rows -= (last_tile + 1) * p->row_tile - p->height;
+    return rows;
+}
+
+int32_t rtamd_global_row(const rtamd_render_params *p, int32_t local_row) {
+    if (!p || p->row_tile < 1 || p->num_parts < 1) return -1;
+    const int tile = local_row / p->row_tile;
+    return (tile * p->num_parts + p->part) * p->row_tile + (local_row - tile * p->row_tile);
+}
+
+int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *build, rtamd_scene **out) {
+    if (!d || !out) return fail(RTAMD_ERR_INVALID, "null scene description or output pointer");
+    *out = nullptr;
+    if (d->num_vertices < 0 || d->num_faces < 0 || d->num_materials < 0 || d->num_lights < 0 || d->num_spheres < 0 || d->samples_per_light < 0)
+        return fail(RTAMD_ERR_INVALID, "negative count in scene description");
+    if (d->num_faces > 0 && (!d->vertices || !d->normals || !d->face_vertex_ids || !d->face_normals || !d->face_origin_distance || !d->face_material_ids))
+        return fail(RTAMD_ERR_INVALID, "null mesh array");
+    if (d->num_faces >= (1 << 27)) return fail(RTAMD_ERR_LIMIT, "%d faces exceed the 2^27 limit", d->num_faces);
+    if ((d->num_materials > 0 && !d->materials) || (d->num_lights > 0 && (!d->light_positions || !d->light_samples)) ||
+        (d->num_spheres > 0 && !d->spheres))
+        return fail(RTAMD_ERR_INVALID, "null material, light or sphere array");
+    if ((int64_t)d->num_lights * d->samples_per_light > kMaxShadowRays)
+        return fail(RTAMD_ERR_LIMIT, "%d lights x %d samples exceed %d shadow rays per hit", d->num_lights, d->samples_per_light, kMaxShadowRays);
+    for (int32_t f = 0; f < d->num_faces; ++f) {
+        for (int k = 0; k < 3; ++k) {
+            const int32_t id = d->face_vertex_ids[3 * (size_t)f + k];
+            if (id < 0 || id >= d->num_vertices) return fail(RTAMD_ERR_INVALID, "face %d references vertex %d of %d", f, id, d->num_vertices);
+        }
+        const int32_t m = d->face_material_ids[f];
+        if (m < -1 || m >= d->num_materials) return fail(RTAMD_ERR_INVALID, "face %d references material %d of %d", f, m, d->num_materials);
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RTAMD_ERR_NO_DEVICE, "no HIP device available");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RTAMD_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", dev, prop.gcnArchName);
+
+    rtamd_scene *s = new (std::nothrow) rtamd_scene();
+    if (!s) return fail(RTAMD_ERR_INVALID, "out of host memory");
+    s->device = dev;
+
+    // ---- host build
+    const double t0 = now_ms();
+    MeshView mesh{d->vertices, d->num_vertices, d->face_vertex_ids, d->face_normals, d->face_origin_distance, d->num_faces};
+    std::vector<int32_t> rank;
+    reference_face_rank(mesh, rank);
+    FlatBvh bvh;
+    build_flat_bvh(mesh, rank, build ? build->max_leaf_faces : 0, build ? build->sah_bins : 0, bvh);
+    if (bvh.depth > kStackEntries) {
+        delete s;
+        return fail(RTAMD_ERR_LIMIT, "BVH depth %d exceeds the traversal stack (%d)", bvh.depth, kStackEntries);
+    }
+    std::vector<ShadeRecord> shade((size_t)d->num_faces);
+    for (int32_t f = 0; f < d->num_faces; ++f) {
+        ShadeRecord &r = shade[f];
+        std::memset(&r, 0, sizeof r);
+        const int32_t *id = d->face_vertex_ids + 3 * (size_t)f;
+        std::memcpy(r.v0, d->vertices + 3 * (size_t)id[0], 12);
+        std::memcpy(r.v1, d->vertices + 3 * (size_t)id[1], 12);
+        std::memcpy(r.v2, d->vertices + 3 * (size_t)id[2], 12);
+        std::memcpy(r.n0, d->normals + 3 * (size_t)id[0], 12);
+        std::memcpy(r.n1, d->normals + 3 * (size_t)id[1], 12);
+        std::memcpy(r.n2, d->normals + 3 * (size_t)id[2], 12);
+        std::memcpy(r.fn, d->face_normals + 3 * (size_t)f, 12);
+        r.material = d->face_material_ids[f];
+    }
+    const double t1 = now_ms();
+
+    // ---- upload
+    uint64_t bytes = 0;
+    int rc = RTAMD_OK;
+    std::vector<float> mats((size_t)d->num_materials * 10);
+    for (int32_t i = 0; i < d->num_materials; ++i) {
+        std::memcpy(&mats[10 * (size_t)i], d->materials[i].ka, 12);
+        std::memcpy(&mats[10 * (size_t)i + 3], d->materials[i].kd, 12);
+        std::memcpy(&mats[10 * (size_t)i + 6], d->materials[i].ks, 12);
+        mats[10 * (size_t)i + 9] = d->materials[i].shininess;
+    }
+    std::vector<float> lpos(d->light_positions, d->light_positions + 3 * (size_t)d->num_lights);
+    std::vector<float> samples(d->light_samples, d->light_samples + 3 * (size_t)d->num_lights * d->samples_per_light);
+    std::vector<rtamd_sphere> spheres(d->spheres, d->spheres + d->num_spheres);
+    if (rc == RTAMD_OK) rc = upload(&s->d_nodes, bvh.nodes, &bytes);
+    if (rc == RTAMD_OK) rc = upload(&s->d_tris, bvh.tris, &bytes);
+    if (rc == RTAMD_OK) rc = upload(&s->d_shade, shade, &bytes);
+    if (rc == RTAMD_OK) rc = upload(&s->d_materials, mats, &bytes);
+    if (rc == RTAMD_OK) rc = upload(&s->d_light_pos, lpos, &bytes);
+    if (rc == RTAMD_OK) rc = upload(&s->d_samples, samples, &bytes);
+    if (rc == RTAMD_OK) rc = upload(&s->d_spheres, spheres, &bytes);
+    if (rc != RTAMD_OK) {
+        rtamd_scene_destroy(s);
+        return rc;
+    }
+    const double t2 = now_ms();
+
+    s->ds.nodes = (const float4 *)s->d_nodes;
+    s->ds.tris = (const float4 *)s->d_tris;
+    s->ds.shade = (const float4 *)s->d_shade;
+    s->ds.materials = (const float *)s->d_materials;
+    s->ds.light_pos = (const float *)s->d_light_pos;
+    s->ds.samples = (const float *)s->d_samples;
+    s->ds.spheres = (const float4 *)s->d_spheres;
+    s->ds.num_lights = d->num_lights;
+    s->ds.spl = d->samples_per_light;
+    s->ds.num_spheres = d->num_spheres;
+    s->ds.num_materials = d->num_materials;
+    s->materials.assign(d->materials, d->materials + d->num_materials);
+
+    s->info.num_faces = d->num_faces;
+    s->info.num_device_faces = bvh.num_device_faces;
+    s->info.num_nodes = (int32_t)bvh.nodes.size();
+    s->info.num_leaves = bvh.num_leaves;
+    s->info.depth = bvh.depth;
+    s->info.device = dev;
+    s->info.device_bytes = bytes;
+    s->info.build_ms = (float)(t1 - t0);
+    s->info.upload_ms = (float)(t2 - t1);
+    *out = s;
+    return RTAMD_OK;
+}
+
+int rtamd_scene_destroy(rtamd_scene *s) {
+    if (!s) return RTAMD_OK;
+    void *bufs[] = {s->d_nodes, s->d_tris, s->d_shade, s->d_materials, s->d_light_pos, s->d_samples, s->d_spheres, s->ws_block, s->d_rgb, s->d_face};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    for (TimedLaunch &t : s->events) {
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+    }
+    if (s->frame_start) (void)hipEventDestroy(s->frame_start);
+    if (s->frame_stop) (void)hipEventDestroy(s->frame_stop);
+    delete s;
+    return RTAMD_OK;
+}
+
+int rtamd_scene_get_info(const rtamd_scene *s, rtamd_scene_info *info) {
+    if (!s || !info) return fail(RTAMD_ERR_INVALID, "null scene or info");
+    *info = s->info;
+    return RTAMD_OK;
+}
+
+int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_render_params *p, float *rgb, int32_t *face_id, float *t_hit,
+                        void *hip_stream) {
+    int rc = check_params(s, cam, p);
+    if (rc != RTAMD_OK) return rc;
+    if (!rgb) return fail(RTAMD_ERR_INVALID, "null rgb output");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != s->device) return fail(RTAMD_ERR_INVALID, "scene lives on device %d but device %d is current", s->device, dev);
+    hipStream_t stream = (hipStream_t)hip_stream;
+
+    const int local_rows = rtamd_local_rows(p);
+    const size_t pixels = (size_t)local_rows * (size_t)p->width;
+    const int S = p->ssaa_level;
+    const int depths = (any_reflective(s, p->reflect_threshold) ? p->max_reflections : 0) + 1;
+    const int stages = S * S * depths;
+    if (stages > kMaxStages) return fail(RTAMD_ERR_LIMIT, "ssaa^2 * (max_reflections + 1) = %d exceeds %d", stages, kMaxStages);
+    s->have_frame = false;
+    if (pixels == 0) return RTAMD_OK;
+    rc = ensure_workspace(s, pixels);
+    if (rc != RTAMD_OK) return rc;
+
+    FrameConst fc;
+    std::memset(&fc, 0, sizeof fc);
+    std::memcpy(fc.origin, cam->origin, sizeof fc.origin);
+    std::memcpy(fc.inv_view, cam->inv_view, sizeof fc.inv_view);
+    std::memcpy(fc.vp, cam->viewport, sizeof fc.vp);
+    // Camera::getPerspectiveScale and its reciprocal, camera.hpp:168,271-274 (double intermediates)
+    const float persp = (float)((double)1.0f / std::tan((double)(cam->fovy / 2.0f) * (M_PI / (double)180.0f)));
+    fc.scale = (float)(1.0 / (double)persp);
+    fc.ax = cam->aspect_ratio * fc.scale;
+    fc.width = p->width, fc.height = p->height, fc.local_rows = local_rows;
+    fc.row_tile = p->row_tile, fc.num_parts = p->num_parts, fc.part = p->part;
+    fc.t_eps = p->t_epsilon, fc.refl_thresh = p->reflect_threshold, fc.bounce_off = p->bounce_offset;
+    std::memcpy(fc.bg, p->background, sizeof fc.bg);
+    std::memcpy(fc.bg_deep, p->background_deep, sizeof fc.bg_deep);
+
+    const bool count = (p->flags & RTAMD_FLAG_COUNT_WORK) != 0;
+    const bool timed = (p->flags & RTAMD_FLAG_TIME_KERNELS) != 0;
+    s->events_used = 0;
+    auto begin = [&](int kind) -> int {
+        if (!timed) return RTAMD_OK;
+        if (s->events_used == s->events.size()) {
+            TimedLaunch t;
+            t.kind = kind;
+            HIP_TRY(hipEventCreate(&t.start));
+            HIP_TRY(hipEventCreate(&t.stop));
+            s->events.push_back(t);
+        }
+        s->events[s->events_used].kind = kind;
+        HIP_TRY(hipEventRecord(s->events[s->events_used].start, stream));
+        return RTAMD_OK;
+    };
+    auto end = [&]() -> int {
+        if (!timed) return RTAMD_OK;
+        HIP_TRY(hipEventRecord(s->events[s->events_used].stop, stream));
+        ++s->events_used;
+        return RTAMD_OK;
+    };
+    if (timed) {
+        if (!s->frame_start) {
+            HIP_TRY(hipEventCreate(&s->frame_start));
+            HIP_TRY(hipEventCreate(&s->frame_stop));
+        }
+        HIP_TRY(hipEventRecord(s->frame_start, stream));
+    }
+
+    HIP_TRY(hipMemsetAsync(s->ws_block, 0, 4096, stream));
+    int stage = 0;
+    for (int xs = 0; xs < S; ++xs)
+        for (int ys = 0; ys < S; ++ys) {
+            fc.sub_x = (float)xs / S; // src/flyscene.cpp:816-817
+            fc.sub_y = (float)ys / S;
+            fc.accumulate = (xs | ys) != 0;
+            for (int d = 0; d < depths; ++d, ++stage) {
+                if ((rc = begin(0)) != RTAMD_OK) return rc;
+                launch_trace(d == 0, count, s->ds, fc, s->ws, stage, d & 1, rgb, face_id, t_hit, stream);
+                if ((rc = end()) != RTAMD_OK) return rc;
+                if ((rc = begin(1)) != RTAMD_OK) return rc;
+                launch_shade(d == 0, count, s->ds, fc, s->ws, stage, d & 1, d + 1 < depths, rgb, stream);
+                if ((rc = end()) != RTAMD_OK) return rc;
+            }
+        }
+    if (S > 1) {
+        if ((rc = begin(2)) != RTAMD_OK) return rc;
+        launch_scale(rgb, pixels * 3, (float)(S * S), stream);
+        if ((rc = end()) != RTAMD_OK) return rc;
+    }
+    if (timed) HIP_TRY(hipEventRecord(s->frame_stop, stream));
+    HIP_TRY(hipGetLastError());
+
+    s->last = *p;
+    s->last_stages = stages;
+    s->last_depths = depths;
+    s->last_primary = (uint64_t)pixels * (uint64_t)(S * S);
+    s->last_stream = stream;
+    s->have_frame = true;
+    return RTAMD_OK;
+}
+
+int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
+    if (!s || !st) return fail(RTAMD_ERR_INVALID, "null scene or stats");
+    std::memset(st, 0, sizeof *st);
+    if (!s->have_frame) return RTAMD_OK;
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    std::vector<StageCounters> sc((size_t)kMaxStages);
+    WorkCounters wc;
+    HIP_TRY(hipMemcpy(sc.data(), s->ws.stage, sizeof(StageCounters) * kMaxStages, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&wc, s->ws.work, sizeof wc, hipMemcpyDeviceToHost));
+    st->rays_primary = s->last_primary;
+    const uint64_t per_hit = (uint64_t)s->ds.num_lights * (uint64_t)s->ds.spl;
+    for (int i = 0; i < s->last_stages; ++i) {
+        st->hits += (uint64_t)sc[i].hits;
+        st->rays_shadow += (uint64_t)sc[i].hits * per_hit;
+        st->rays_bounce += (uint64_t)sc[i].next;
+    }
+    st->box_tests = wc.box_tests;
+    st->tri_plane = wc.tri_plane;
+    st->tri_edge = wc.tri_edge;
+    if ((s->last.flags & RTAMD_FLAG_TIME_KERNELS) && s->frame_start) {
+        for (size_t i = 0; i < s->events_used; ++i) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, s->events[i].start, s->events[i].stop));
+            if (s->events[i].kind == 0) st->ms_trace += ms, ++st->launches_trace;
+            if (s->events[i].kind == 1) st->ms_shade += ms, ++st->launches_shade;
+        }
+        HIP_TRY(hipEventElapsedTime(&st->ms_total, s->frame_start, s->frame_stop));
+    }
+    return RTAMD_OK;
+}
+
+int rtamd_render(rtamd_scene *s, const rtamd_camera *cam, const rtamd_render_params *p, float *rgb, int32_t *face_id, rtamd_stats *stats) {
+    int rc = check_params(s, cam, p);
+    if (rc != RTAMD_OK) return rc;
+    if (!rgb) return fail(RTAMD_ERR_INVALID, "null rgb output");
+    const size_t pixels = (size_t)rtamd_local_rows(p) * (size_t)p->width;
+    if (pixels == 0) {
+        if (stats) std::memset(stats, 0, sizeof *stats);
+        return RTAMD_OK;
+    }
+    if (s->staging_pixels < pixels) {
+        if (s->d_rgb) HIP_TRY(hipFree(s->d_rgb));
+        if (s->d_face) HIP_TRY(hipFree(s->d_face));
+        s->d_rgb = nullptr, s->d_face = nullptr, s->staging_pixels = 0;
+        HIP_TRY(hipMalloc((void **)&s->d_rgb, pixels * 12));
+        HIP_TRY(hipMalloc((void **)&s->d_face, pixels * 4));
+        s->staging_pixels = pixels;
+    }
+    rc = rtamd_render_device(s, cam, p, s->d_rgb, face_id ? s->d_face : nullptr, nullptr, nullptr);
+    if (rc != RTAMD_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpy(rgb, s->d_rgb, pixels * 12, hipMemcpyDeviceToHost));
+    if (face_id) HIP_TRY(hipMemcpy(face_id, s->d_face, pixels * 4, hipMemcpyDeviceToHost));
+    if (stats) return rtamd_render_stats(s, stats);
+    return RTAMD_OK;
+}
+
+int rtamd_assemble_rows(const rtamd_render_params *p, const void *src, void *dst, int32_t channels, void *hip_stream) {
+    if (!p || !src || !dst) return fail(RTAMD_ERR_INVALID, "null argument");
+    if (p->width <= 0 || p->height <= 0 || channels <= 0 || p->row_tile < 1 || p->num_parts < 1)
+        return fail(RTAMD_ERR_INVALID, "bad image or partition");
+    launch_assemble(src, dst, p->width, p->height, channels, p->row_tile, p->num_parts, (hipStream_t)hip_stream);
+    HIP_TRY(hipGetLastError());
+    return RTAMD_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,62 @@
+// Plain structs shared by the host orchestration (api.cpp) and the gfx950 kernels (kernels.hip).
+#pragma once
+#include <cstdint>
+
+namespace rtamd {
+
+constexpr int kStackEntries = 32;   // per-lane traversal stack in LDS; the builder bounds the tree depth to this
+constexpr int kShadeWaves = 4;      // waves per workgroup of the shading kernel
+constexpr int kMaxShadowRays = 512; // lights * samples_per_light handled by one shading workgroup
+constexpr int kMaxStages = 64;      // (ssaa passes) * (max_reflections + 1) counter slots per frame
+
+// Read-only scene in HBM.
+struct DeviceScene {
+    const float4 *nodes;      // 4 x float4 per BvhNode
+    const float4 *tris;       // 4 x float4 per TriRecord
+    const float4 *shade;      // 6 x float4 per ShadeRecord, indexed by face
+    const float *materials;   // 10 floats per material: ka, kd, ks, shininess
+    const float *light_pos;   // 3 per light
+    const float *samples;     // 3 per (light, sample)
+    const float4 *spheres;    // center, radius
+    int32_t num_lights, spl, num_spheres, num_materials;
+};
+
+// Per-launch constants (camera + the reference's macros).
+struct FrameConst {
+    float origin[3];
+    float inv_view[12];
+    float vp[4];
+    float ax;    // aspect_ratio * scale   (camera.hpp:169)
+    float scale; // 1 / perspective scale  (camera.hpp:168)
+    float sub_x, sub_y; // sub-sample offset of this SSAA pass (src/flyscene.cpp:816-817)
+    int32_t width, height, local_rows;
+    int32_t row_tile, num_parts, part;
+    float t_eps, refl_thresh, bounce_off;
+    float bg[3], bg_deep[3];
+    int32_t accumulate; // 0: first SSAA pass stores the pixel, 1: later passes add to it
+};
+
+// Per-stage counters, zeroed once per frame.
+struct StageCounters {
+    int32_t hits;  // entries of the hit list written by the trace kernel
+    int32_t next;  // rays appended to the next queue by the shading kernel
+};
+
+struct WorkCounters {
+    unsigned long long box_tests, tri_plane, tri_edge, pad;
+};
+
+// Work buffers in HBM, sized for `capacity` ray slots (= pixels of the local image).
+struct Workspace {
+    int32_t capacity;
+    // hit list of the current stage (positions 0..hits-1)
+    int32_t *hit_slot; // ray slot: pixel index (primary) or queue index (bounce)
+    int32_t *hit_tri;  // TriRecord index, or -1 for a sphere
+    float *hit_p;      // 3 planes of `capacity`: hit point
+    // ray queues, ping-pong; 10 planes of `capacity` each: o.xyz, d.xyz, throughput.rgb, pixel(bits)
+    float *queue[2];
+    StageCounters *stage; // kMaxStages
+    WorkCounters *work;
+};
+
+} // namespace rtamd

@@ -1,0 +1,667 @@
+#include "flyscene_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "../../include/rtamd_flyscene.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace rtamd {
+
+namespace {
+
+// Fixed-size float vector helpers in Eigen's evaluation order (3-term sums associate x + (y + z)).
+struct F3 {
+    float x, y, z;
+};
+inline F3 f3(const float *p) { return F3{p[0], p[1], p[2]}; }
+inline F3 sub(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline float dot(F3 a, F3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+inline F3 cross(F3 a, F3 b) { return F3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline F3 unit(F3 a) {
+    const float z = dot(a, a);
+    if (z > 0.0f) {
+        const float s = std::sqrt(z);
+        return F3{a.x / s, a.y / s, a.z / s};
+    }
+    return a;
+}
+inline void put(float *p, F3 a) { p[0] = a.x, p[1] = a.y, p[2] = a.z; }
+
+void erase_crlf(std::string &s) {
+    s.erase(std::remove(s.begin(), s.end(), '\n'), s.end());
+    s.erase(std::remove(s.begin(), s.end(), '\r'), s.end());
+}
+
+std::string directory_of(const std::string &path) {
+    const size_t cut = path.find_last_of("/\\");
+    return cut == std::string::npos ? std::string() : path.substr(0, cut + 1);
+}
+
+rtamd_material default_material() { // materials/mtl.hpp:22-31
+    rtamd_material m;
+    for (int i = 0; i < 3; ++i) m.ka[i] = (float)0.3, m.kd[i] = (float)0.5, m.ks[i] = (float)1.0;
+    m.shininess = 10;
+    return m;
+}
+
+// Face::normal, mesh.hpp:475-477: unit cross product of the two unit edge vectors, file coordinates.
+F3 raw_face_normal(const HostMesh &m, const int32_t *id) {
+    const F3 p0 = f3(&m.vertices[3 * (size_t)id[0]]), p1 = f3(&m.vertices[3 * (size_t)id[1]]), p2 = f3(&m.vertices[3 * (size_t)id[2]]);
+    const F3 e1 = unit(sub(p2, p0));
+    const F3 e0 = unit(sub(p1, p0));
+    return unit(cross(e0, e1));
+}
+
+} // namespace
+
+// utils/mtlIO.hpp:49-140.  Records are split on single blanks, exactly like std::getline(ss, s, ' ').
+bool load_mtl(const std::string &path, std::vector<NamedMaterial> &materials) {
+    std::ifstream in(path.c_str());
+    if (!in) {
+        std::fprintf(stderr, "Cannot open %s\n", path.c_str());
+        return false;
+    }
+    std::string line;
+    while (std::getline(in, line)) {
+        if (line.empty()) continue;
+        std::vector<std::string> tok;
+        size_t pos = 0;
+        while (pos < line.size()) {
+            const size_t sp = line.find(' ', pos);
+            if (sp == std::string::npos) {
+                tok.push_back(line.substr(pos));
+                break;
+            }
+            tok.push_back(line.substr(pos, sp - pos));
+            pos = sp + 1;
+        }
+        if (tok.empty()) continue;
+        auto num = [&](size_t i) { return i < tok.size() ? (float)std::atof(tok[i].c_str()) : 0.0f; };
+        const std::string &key = tok[0];
+        if (key == "#") continue;
+        if (key == "newmtl") {
+            NamedMaterial nm;
+            nm.m = default_material();
+            nm.name = tok.size() > 1 ? tok[1] : std::string();
+            erase_crlf(nm.name);
+            materials.push_back(nm);
+        } else if (!materials.empty()) {
+            rtamd_material &m = materials.back().m;
+            if (key == "Ns") {
+                m.shininess = num(1);
+            } else if (key == "Ka") {
+                m.ka[0] = num(1), m.ka[1] = num(2), m.ka[2] = num(3);
+            } else if (key == "Kd") {
+                m.kd[0] = num(1), m.kd[1] = num(2), m.kd[2] = num(3);
+            } else if (key == "Ks") {
+                m.ks[0] = num(1), m.ks[1] = num(2), m.ks[2] = num(3);
+            }
+            // Ni, d, illum and map_kd are parsed by the reference but not read by the traced path
+        }
+    }
+    if (materials.empty()) { // :130-134
+        NamedMaterial nm;
+        nm.m = default_material();
+        materials.push_back(nm);
+    }
+    return true;
+}
+
+// Vertex normals when the file gives none (or a different count): objimporter.hpp:81-106.
+static void accumulate_vertex_normals(HostMesh &m) {
+    std::fill(m.normals.begin(), m.normals.end(), 0.0f);
+    const int32_t nf = m.num_faces();
+    for (int32_t f = 0; f < nf; ++f) {
+        const int32_t *id = &m.face_vertex[3 * (size_t)f];
+        const F3 n = raw_face_normal(m, id);
+        for (int k = 0; k < 3; ++k) {
+            float *d = &m.normals[3 * (size_t)id[k]];
+            d[0] += n.x, d[1] += n.y, d[2] += n.z;
+        }
+    }
+    for (int32_t i = 0; i < m.num_vertices(); ++i) put(&m.normals[3 * (size_t)i], unit(f3(&m.normals[3 * (size_t)i])));
+}
+
+void finish_mesh(HostMesh &m, bool have_normals) {
+    m.normals.resize(m.vertices.size(), 0.0f);
+    if (!have_normals) accumulate_vertex_normals(m);
+    const int32_t nf = m.num_faces();
+    m.face_normal.assign(3 * (size_t)nf, 0.0f);
+    for (int32_t f = 0; f < nf; ++f) put(&m.face_normal[3 * (size_t)f], raw_face_normal(m, &m.face_vertex[3 * (size_t)f]));
+}
+
+// utils/objimporter.hpp:117-351 + Mesh::createFaces (mesh.hpp:448-482).
+//  * faces are numbered in the order of the `f` records (index groups per `usemtl` are appended in
+//    file order and emitted group by group);
+//  * every element of an `f` record contributes its vertex index -- no triangulation; faces are the
+//    consecutive index triples of each group;
+//  * the normal and texture indices of `f` records are ignored: `vn` k belongs to `v` k when the
+//    counts agree, otherwise vertex normals are recomputed from the faces.
+bool load_obj(const std::string &path, HostMesh &mesh, std::string &error) {
+    std::ifstream in(path.c_str());
+    if (!in) {
+        error = "Cannot open " + path;
+        return false;
+    }
+    mesh = HostMesh();
+    const std::string dir = directory_of(path);
+    std::vector<float> file_normals;
+    std::vector<std::vector<int32_t>> groups(1);
+    std::vector<int32_t> group_material(1, -1);
+    int32_t current_material = -1;
+    std::string line;
+    while (std::getline(in, line)) {
+        if (line.compare(0, 6, "mtllib") == 0 && line.size() >= 7) {
+            std::string fn = dir + line.substr(7);
+            erase_crlf(fn);
+            load_mtl(fn, mesh.materials);
+        } else if (line.compare(0, 6, "usemtl") == 0 && line.size() >= 7) {
+            if (!groups.back().empty()) {
+                groups.emplace_back();
+                group_material.push_back(-1);
+            }
+            std::string name = line.substr(7);
+            erase_crlf(name);
+            for (size_t i = 0; i < mesh.materials.size(); ++i)
+                if (mesh.materials[i].name == name) current_material = (int32_t)i; // sticky when not found
+            group_material.back() = current_material;
+        } else if (line.compare(0, 2, "v ") == 0) {
+            const char *p = line.c_str() + 2;
+            char *e;
+            for (int k = 0; k < 3; ++k) {
+                mesh.vertices.push_back(std::strtof(p, &e));
+                p = e;
+            }
+        } else if (line.compare(0, 2, "vn") == 0) {
+            const char *p = line.c_str() + std::min<size_t>(3, line.size());
+            char *e;
+            for (int k = 0; k < 3; ++k) {
+                file_normals.push_back(std::strtof(p, &e));
+                p = e;
+            }
+        } else if (line.compare(0, 2, "f ") == 0) {
+            std::istringstream els(line.substr(2));
+            std::string el;
+            while (els >> el) groups.back().push_back((int32_t)std::strtol(el.c_str(), nullptr, 10) - 1);
+        }
+    }
+    const int32_t nv = mesh.num_vertices();
+    for (size_t g = 0; g < groups.size(); ++g)
+        for (size_t i = 0; i + 2 < groups[g].size(); i += 3) {
+            for (int k = 0; k < 3; ++k) {
+                const int32_t id = groups[g][i + k];
+                if (id < 0 || id >= nv) {
+                    error = "face references vertex " + std::to_string(id + 1) + " of " + std::to_string(nv) + " in " + path;
+                    return false;
+                }
+                mesh.face_vertex.push_back(id);
+            }
+            mesh.face_material.push_back(group_material[g]);
+        }
+    const bool paired = (int32_t)(file_normals.size() / 3) == nv && nv > 0;
+    if (paired) mesh.normals = file_normals;
+    finish_mesh(mesh, paired);
+    return true;
+}
+
+// utils/ppmIO.hpp:188-209: ASCII P3, each channel min(255, (int)(255 * c)), one text line per row.
+bool write_ppm(const std::string &path, const float *rgb, int width, int height) {
+    std::FILE *out = std::fopen(path.c_str(), "w");
+    if (!out) return false;
+    std::string buf;
+    buf.reserve((size_t)width * 12 + 16);
+    std::fprintf(out, "P3\n%d %d\n255\n", width, height);
+    char tmp[48];
+    for (int j = 0; j < height; ++j) {
+        buf.clear();
+        for (int i = 0; i < width; ++i) {
+            const float *p = rgb + 3 * ((size_t)j * width + i);
+            const int r = std::min(255, (int)(255 * p[0])), g = std::min(255, (int)(255 * p[1])), b = std::min(255, (int)(255 * p[2]));
+            const int n = std::snprintf(tmp, sizeof tmp, "%d %d %d ", r, g, b);
+            buf.append(tmp, (size_t)n);
+        }
+        buf.push_back('\n');
+        std::fwrite(buf.data(), 1, buf.size(), out);
+    }
+    std::fclose(out);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Flycamera
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+void mat3_inverse(const float *m /*row-major 3x4, linear part*/, float *inv /*3x3 row-major*/) {
+    const float a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    const float c00 = e * i - f * h, c01 = f * g - d * i, c02 = d * h - e * g;
+    const float det = a * c00 + b * c01 + c * c02;
+    const float r = 1.0f / det;
+    inv[0] = c00 * r, inv[1] = (c * h - b * i) * r, inv[2] = (b * f - c * e) * r;
+    inv[3] = c01 * r, inv[4] = (a * i - c * g) * r, inv[5] = (c * d - a * f) * r;
+    inv[6] = c02 * r, inv[7] = (b * g - a * h) * r, inv[8] = (a * e - b * d) * r;
+}
+
+// rotation by `angle` about unit axis `ax` (Rodrigues, as Eigen::AngleAxisf::toRotationMatrix)
+void axis_angle(const float *ax, float angle, float *R) {
+    const float s = std::sin(angle), c = std::cos(angle), t = 1.0f - c;
+    const float x = ax[0], y = ax[1], z = ax[2];
+    R[0] = t * x * x + c, R[1] = t * x * y - s * z, R[2] = t * x * z + s * y;
+    R[3] = t * x * y + s * z, R[4] = t * y * y + c, R[5] = t * y * z - s * x;
+    R[6] = t * x * z - s * y, R[7] = t * y * z + s * x, R[8] = t * z * z + c;
+}
+void mul3(const float *R, const float *v, float *o) {
+    for (int r = 0; r < 3; ++r) o[r] = R[3 * r] * v[0] + R[3 * r + 1] * v[1] + R[3 * r + 2] * v[2];
+}
+void norm3(float *v) {
+    const float z = v[0] * v[0] + (v[1] * v[1] + v[2] * v[2]);
+    if (z > 0.0f) {
+        const float s = std::sqrt(z);
+        v[0] /= s, v[1] /= s, v[2] /= s;
+    }
+}
+
+} // namespace
+
+void Flycamera::reset() {
+    translation_[0] = translation_[1] = translation_[2] = 0.0f;
+    rot_x_ = rot_y_ = 0.0f;
+    updateViewMatrix();
+    reComputeViewMatrix();
+}
+
+void Flycamera::setPerspectiveMatrix(float fovy, float aspect, float, float) {
+    fovy_ = fovy;
+    aspect_ = aspect;
+}
+
+void Flycamera::setViewport(float w, float h) {
+    viewport_[0] = viewport_[1] = 0.0f;
+    viewport_[2] = w, viewport_[3] = h;
+}
+
+void Flycamera::translate(float dx, float dy, float dz) {
+    const float up[3] = {0, 1, 0};
+    float Y[9];
+    axis_angle(up, rot_y_, Y);
+    const float v[3] = {-dx, -dy, dz};
+    float o[3];
+    mul3(Y, v, o);
+    for (int k = 0; k < 3; ++k) translation_[k] += o[k] * speed_;
+}
+
+void Flycamera::rotate(float angle_x, float angle_y) {
+    rot_x_ += angle_x;
+    rot_y_ += angle_y;
+}
+
+// view = Rotate(default_rotation = I) * Rotate(rotation_matrix) * Translate(0,0,-2) * Translate(translation)
+void Flycamera::updateViewMatrix() {
+    const float ux[3] = {1, 0, 0}, uy[3] = {0, 1, 0}, uz[3] = {0, 0, 1};
+    float Y[9], X[9], rotX[3], rotY[3], rotZ[3], tmp[3];
+    axis_angle(uy, rot_y_, Y);
+    mul3(Y, ux, rotX);
+    norm3(rotX);
+    mul3(Y, uz, tmp);
+    axis_angle(rotX, rot_x_, X);
+    mul3(X, tmp, rotZ);
+    norm3(rotZ);
+    mul3(X, uy, rotY);
+    norm3(rotY);
+    const float R[9] = {rotX[0], rotX[1], rotX[2], rotY[0], rotY[1], rotY[2], rotZ[0], rotZ[1], rotZ[2]};
+    const float t[3] = {0.0f + translation_[0], 0.0f + translation_[1], -2.0f + translation_[2]};
+    for (int r = 0; r < 3; ++r) {
+        for (int k = 0; k < 3; ++k) view_[4 * r + k] = R[3 * r + k];
+        view_[4 * r + 3] = R[3 * r] * t[0] + R[3 * r + 1] * t[1] + R[3 * r + 2] * t[2];
+    }
+}
+
+void Flycamera::reComputeViewMatrix() {
+    float inv[9];
+    mat3_inverse(view_, inv);
+    for (int r = 0; r < 3; ++r) {
+        for (int k = 0; k < 3; ++k) inv_view_[4 * r + k] = inv[3 * r + k];
+        // -(L^-1 * t)
+        inv_view_[4 * r + 3] = -(inv[3 * r] * view_[3] + inv[3 * r + 1] * view_[7] + inv[3 * r + 2] * view_[11]);
+    }
+}
+
+std::array<float, 3> Flycamera::getCenter() const {
+    float inv[9];
+    mat3_inverse(view_, inv);
+    std::array<float, 3> c;
+    for (int r = 0; r < 3; ++r) c[r] = inv[3 * r] * -view_[3] + inv[3 * r + 1] * -view_[7] + inv[3 * r + 2] * -view_[11];
+    return c;
+}
+
+void Flycamera::fill(rtamd_camera &c) const {
+    const std::array<float, 3> o = getCenter();
+    // +0.0 so that a negative zero from the sign flips above never reaches the ray origin
+    for (int k = 0; k < 3; ++k) c.origin[k] = o[k] + 0.0f;
+    for (int k = 0; k < 12; ++k) c.inv_view[k] = inv_view_[k] + 0.0f;
+    std::memcpy(c.viewport, viewport_, sizeof c.viewport);
+    c.aspect_ratio = aspect_;
+    c.fovy = fovy_;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Flyscene
+// ------------------------------------------------------------------------------------------------
+Flyscene::~Flyscene() {
+    if (scene_) rtamd_scene_destroy(scene_);
+}
+
+void Flyscene::loadLightsAndSpheres() {
+    if (lights_defaulted) return;
+    lights_defaulted = true;
+    lights.insert(lights.begin(), Light{{-1.0f, 1.0f, 1.0f}, {1.0f, 1.0f, 1.0f}}); // src/flyscene.cpp:9
+}
+
+void Flyscene::precomputeData() {
+    const int32_t nv = mesh.num_vertices(), nf = mesh.num_faces();
+    // Mesh::loadVertices (mesh.hpp:610-628) + Model::normalizeModelMatrix (model.hpp:169-173)
+    float s = 1.0f, c[3] = {0, 0, 0};
+    if (nv > 0) {
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) lo[a] = hi[a] = mesh.vertices[a];
+        for (int32_t i = 0; i < nv; ++i)
+            for (int a = 0; a < 3; ++a) {
+                hi[a] = std::max(mesh.vertices[3 * (size_t)i + a], hi[a]);
+                lo[a] = std::min(mesh.vertices[3 * (size_t)i + a], lo[a]);
+            }
+        const float ext = std::max(std::max(std::fabs(hi[0] - lo[0]), std::fabs(hi[1] - lo[1])), std::fabs(hi[2] - lo[2]));
+        s = (float)(1.0 / (double)ext);
+        for (int a = 0; a < 3; ++a) c[a] = (float)((double)(hi[a] + lo[a]) / 2.0);
+    }
+    std::memset(model_matrix, 0, sizeof model_matrix);
+    if (normalize_model) {
+        model_matrix[0] = model_matrix[5] = model_matrix[10] = s;
+        model_matrix[3] = s * -c[0], model_matrix[7] = s * -c[1], model_matrix[11] = s * -c[2];
+    } else {
+        model_matrix[0] = model_matrix[5] = model_matrix[10] = 1.0f;
+    }
+    // src/flyscene.cpp:165-219.  Entries of vertices never referenced by a face stay zero.
+    P_vertices.assign(3 * (size_t)nv, 0.0f);
+    P_normals.assign(3 * (size_t)nv, 0.0f);
+    P_face_distance.assign((size_t)nf, 0.0f);
+    for (int32_t f = 0; f < nf; ++f) {
+        const int32_t *id = &mesh.face_vertex[3 * (size_t)f];
+        for (int k = 0; k < 3; ++k) {
+            const float *v = &mesh.vertices[3 * (size_t)id[k]];
+            float *o = &P_vertices[3 * (size_t)id[k]];
+            // (shapeModelMatrix * Vector4f(v, 1)).head(3): one multiply and one add per coordinate
+            o[0] = model_matrix[0] * v[0] + model_matrix[3];
+            o[1] = model_matrix[5] * v[1] + model_matrix[7];
+            o[2] = model_matrix[10] * v[2] + model_matrix[11];
+            put(&P_normals[3 * (size_t)id[k]], unit(f3(&mesh.normals[3 * (size_t)id[k]])));
+        }
+        P_face_distance[f] = dot(f3(&mesh.face_normal[3 * (size_t)f]), f3(&P_vertices[3 * (size_t)id[0]])); // :209
+    }
+    plain_materials.clear();
+    for (const NamedMaterial &nm : mesh.materials) plain_materials.push_back(nm.m);
+}
+
+void Flyscene::precomputeLights() {
+    const int spl = (hard_shadow ? 1 : 0) + soft_points;
+    light_samples.assign(3 * lights.size() * (size_t)spl, 0.0f);
+    for (size_t i = 0; i < lights.size(); ++i) {
+        float *out = &light_samples[3 * i * (size_t)spl];
+        const float *lp = lights[i].position;
+        int k = 0;
+        if (hard_shadow) { // :228-233
+            out[0] = lp[0], out[1] = lp[1], out[2] = lp[2];
+            k = 1;
+        }
+        for (int n = 0; n < soft_points; ++n, ++k) { // :240-247
+            const float theta = (2.0f * (float)n * (float)M_PI) / soft_points;
+            const float phi = std::acos(1 - 2 * ((float)n / (soft_points * (float)M_PI)));
+            const float x = soft_radius * std::sin(phi) * std::cos(theta);
+            const float y = soft_radius * std::sin(phi) * std::sin(theta);
+            const float z = soft_radius * std::cos(phi);
+            out[3 * k] = lp[0] + x, out[3 * k + 1] = lp[1] + y, out[3 * k + 2] = lp[2] + z;
+        }
+    }
+}
+
+int Flyscene::upload() {
+    if (scene_) {
+        rtamd_scene_destroy(scene_);
+        scene_ = nullptr;
+    }
+    std::vector<float> lpos, lcol;
+    for (const Light &l : lights) {
+        lpos.insert(lpos.end(), l.position, l.position + 3);
+        lcol.insert(lcol.end(), l.color, l.color + 3);
+    }
+    rtamd_scene_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.vertices = P_vertices.data();
+    d.normals = P_normals.data();
+    d.num_vertices = mesh.num_vertices();
+    d.face_vertex_ids = mesh.face_vertex.data();
+    d.face_normals = mesh.face_normal.data();
+    d.face_origin_distance = P_face_distance.data();
+    d.face_material_ids = mesh.face_material.data();
+    d.num_faces = mesh.num_faces();
+    d.materials = plain_materials.data();
+    d.num_materials = (int32_t)plain_materials.size();
+    d.light_positions = lpos.data();
+    d.light_colors = lcol.data();
+    d.num_lights = (int32_t)lights.size();
+    d.light_samples = light_samples.data();
+    d.samples_per_light = (hard_shadow ? 1 : 0) + soft_points;
+    d.spheres = spheres.data();
+    d.num_spheres = (int32_t)spheres.size();
+    return rtamd_scene_create(&d, &build, &scene_);
+}
+
+int Flyscene::initialize(int width, int height, bool do_upload) {
+    loadLightsAndSpheres();
+    flycamera.setPerspectiveMatrix(60.0f, (float)width / (float)height, 0.1f, 100.0f); // :35
+    flycamera.setViewport((float)width, (float)height);                                  // :36
+    if (!mesh_from_arrays) {
+        std::string err;
+        if (!load_obj(model_path, mesh, err)) {
+            std::fprintf(stderr, "%s\n", err.c_str());
+            return RTAMD_ERR_INVALID;
+        }
+    }
+    if (params.width == 0) rtamd_render_params_default(&params, width, height);
+    params.width = width, params.height = height;
+    precomputeData();
+    precomputeLights();
+    initialized_ = true;
+    return do_upload ? upload() : RTAMD_OK;
+}
+
+int Flyscene::addLight() {
+    const std::array<float, 3> c = flycamera.getCenter();
+    lights.push_back(Light{{c[0], c[1], c[2]}, {1.0f, 1.0f, 1.0f}});
+    if (!initialized_) return RTAMD_OK;
+    precomputeLights();
+    return scene_ ? upload() : RTAMD_OK;
+}
+
+int Flyscene::render(float *rgb, int32_t *face_id, rtamd_stats *stats) {
+    if (!scene_) return RTAMD_ERR_INVALID;
+    flycamera.reComputeViewMatrix(); // tracePixels does this first, src/flyscene.cpp:806
+    rtamd_camera cam;
+    flycamera.fill(cam);
+    return rtamd_render(scene_, &cam, &params, rgb, face_id, stats);
+}
+
+int Flyscene::raytraceScene() {
+    const std::array<int, 2> size = flycamera.getViewportSize(); // :394
+    if (size[0] != params.width || size[1] != params.height) return RTAMD_ERR_INVALID;
+    rtamd_render_params full = params;
+    full.num_parts = 1, full.part = 0;
+    const rtamd_render_params saved = params;
+    params = full;
+    std::vector<float> pixel_data((size_t)size[0] * size[1] * 3);
+    const int rc = render(pixel_data.data(), nullptr, nullptr);
+    params = saved;
+    if (rc != RTAMD_OK) return rc;
+    if (!output_path.empty() && !write_ppm(output_path, pixel_data.data(), size[0], size[1])) return RTAMD_ERR_INVALID;
+    return RTAMD_OK;
+}
+
+} // namespace rtamd
+
+// ------------------------------------------------------------------------------------------------
+// Flat C view
+// ------------------------------------------------------------------------------------------------
+using rtamd::Flyscene;
+
+struct rtfly {
+    Flyscene fly;
+};
+
+extern "C" {
+
+int rtfly_create(rtfly **out) {
+    if (!out) return RTAMD_ERR_INVALID;
+    *out = new rtfly();
+    return RTAMD_OK;
+}
+int rtfly_destroy(rtfly *f) {
+    delete f;
+    return RTAMD_OK;
+}
+int rtfly_set_model(rtfly *f, const char *p) {
+    if (!f || !p) return RTAMD_ERR_INVALID;
+    f->fly.model_path = p;
+    f->fly.mesh_from_arrays = false;
+    return RTAMD_OK;
+}
+int rtfly_set_model_arrays(rtfly *f, const float *v, const float *n, int32_t nv, const int32_t *faces, const int32_t *fm, int32_t nf,
+                           const rtamd_material *mats, int32_t nm) {
+    if (!f || !v || !faces || nv < 0 || nf < 0 || nm < 0) return RTAMD_ERR_INVALID;
+    for (int64_t i = 0; i < 3 * (int64_t)nf; ++i)
+        if (faces[i] < 0 || faces[i] >= nv) return RTAMD_ERR_INVALID;
+    rtamd::HostMesh &m = f->fly.mesh;
+    m = rtamd::HostMesh();
+    m.vertices.assign(v, v + 3 * (size_t)nv);
+    if (n) m.normals.assign(n, n + 3 * (size_t)nv);
+    m.face_vertex.assign(faces, faces + 3 * (size_t)nf);
+    m.face_material.assign((size_t)nf, -1);
+    if (fm) m.face_material.assign(fm, fm + nf);
+    for (int32_t i = 0; i < nm; ++i) m.materials.push_back(rtamd::NamedMaterial{std::string(), mats[i]});
+    rtamd::finish_mesh(m, n != nullptr);
+    f->fly.mesh_from_arrays = true;
+    return RTAMD_OK;
+}
+int rtfly_clear_lights(rtfly *f) {
+    if (!f) return RTAMD_ERR_INVALID;
+    f->fly.lights.clear();
+    f->fly.lights_defaulted = true;
+    return RTAMD_OK;
+}
+int rtfly_add_light_at(rtfly *f, const float *p, const float *c) {
+    if (!f || !p) return RTAMD_ERR_INVALID;
+    rtamd::Light l{{p[0], p[1], p[2]}, {1.0f, 1.0f, 1.0f}};
+    if (c) l.color[0] = c[0], l.color[1] = c[1], l.color[2] = c[2];
+    f->fly.lights.push_back(l);
+    return RTAMD_OK;
+}
+int rtfly_set_shadow_sampling(rtfly *f, int32_t hard, int32_t soft, float radius) {
+    if (!f || soft < 0 || (!hard && soft == 0)) return RTAMD_ERR_INVALID;
+    f->fly.hard_shadow = hard != 0, f->fly.soft_points = soft, f->fly.soft_radius = radius;
+    return RTAMD_OK;
+}
+int rtfly_add_sphere(rtfly *f, const float *c, float r) {
+    if (!f || !c) return RTAMD_ERR_INVALID;
+    f->fly.spheres.push_back(rtamd_sphere{{c[0], c[1], c[2]}, r});
+    return RTAMD_OK;
+}
+int rtfly_set_normalize_model(rtfly *f, int32_t on) {
+    if (!f) return RTAMD_ERR_INVALID;
+    f->fly.normalize_model = on != 0;
+    return RTAMD_OK;
+}
+int rtfly_set_output(rtfly *f, const char *p) {
+    if (!f || !p) return RTAMD_ERR_INVALID;
+    f->fly.output_path = p;
+    return RTAMD_OK;
+}
+int rtfly_set_build_params(rtfly *f, const rtamd_build_params *b) {
+    if (!f || !b) return RTAMD_ERR_INVALID;
+    f->fly.build = *b;
+    return RTAMD_OK;
+}
+int rtfly_initialize(rtfly *f, int32_t w, int32_t h, int32_t upload) {
+    if (!f || w <= 0 || h <= 0) return RTAMD_ERR_INVALID;
+    return f->fly.initialize(w, h, upload != 0);
+}
+int rtfly_add_light(rtfly *f) { return f ? f->fly.addLight() : RTAMD_ERR_INVALID; }
+int rtfly_camera_reset(rtfly *f) {
+    if (!f) return RTAMD_ERR_INVALID;
+    f->fly.getCamera()->reset();
+    return RTAMD_OK;
+}
+int rtfly_camera_translate(rtfly *f, float dx, float dy, float dz) {
+    if (!f) return RTAMD_ERR_INVALID;
+    f->fly.getCamera()->translate(dx, dy, dz);
+    return RTAMD_OK;
+}
+int rtfly_camera_rotate(rtfly *f, float ax, float ay) {
+    if (!f) return RTAMD_ERR_INVALID;
+    f->fly.getCamera()->rotate(ax, ay);
+    return RTAMD_OK;
+}
+int rtfly_camera_update_view(rtfly *f) {
+    if (!f) return RTAMD_ERR_INVALID;
+    f->fly.getCamera()->updateViewMatrix();
+    return RTAMD_OK;
+}
+int rtfly_get_camera(rtfly *f, rtamd_camera *cam) {
+    if (!f || !cam) return RTAMD_ERR_INVALID;
+    f->fly.getCamera()->reComputeViewMatrix();
+    f->fly.getCamera()->fill(*cam);
+    return RTAMD_OK;
+}
+rtamd_render_params *rtfly_params(rtfly *f) { return f ? &f->fly.params : nullptr; }
+int rtfly_raytrace_scene(rtfly *f) { return f ? f->fly.raytraceScene() : RTAMD_ERR_INVALID; }
+int rtfly_raytrace_to(rtfly *f, float *rgb, int32_t *face_id, rtamd_stats *stats) {
+    if (!f || !rgb) return RTAMD_ERR_INVALID;
+    return f->fly.render(rgb, face_id, stats);
+}
+rtamd_scene *rtfly_scene(rtfly *f) { return f ? f->fly.scene() : nullptr; }
+
+int rtfly_get_array(rtfly *f, const char *name, const void **data, int64_t *count) {
+    if (!f || !name || !data || !count) return RTAMD_ERR_INVALID;
+    Flyscene &s = f->fly;
+    const std::string n = name;
+    auto set = [&](const void *p, size_t c) {
+        *data = p;
+        *count = (int64_t)c;
+        return RTAMD_OK;
+    };
+    if (n == "raw_vertices") return set(s.mesh.vertices.data(), s.mesh.vertices.size());
+    if (n == "raw_normals") return set(s.mesh.normals.data(), s.mesh.normals.size());
+    if (n == "vertices") return set(s.P_vertices.data(), s.P_vertices.size());
+    if (n == "normals") return set(s.P_normals.data(), s.P_normals.size());
+    if (n == "face_normals") return set(s.mesh.face_normal.data(), s.mesh.face_normal.size());
+    if (n == "face_origin_distance") return set(s.P_face_distance.data(), s.P_face_distance.size());
+    if (n == "light_samples") return set(s.light_samples.data(), s.light_samples.size());
+    if (n == "materials") return set(s.plain_materials.data(), s.plain_materials.size() * 10);
+    if (n == "model_matrix") return set(s.model_matrix, 12);
+    if (n == "face_vertex_ids") return set(s.mesh.face_vertex.data(), s.mesh.face_vertex.size());
+    if (n == "face_material_ids") return set(s.mesh.face_material.data(), s.mesh.face_material.size());
+    return RTAMD_ERR_INVALID;
+}
+
+int rtfly_write_ppm(const char *path, const float *rgb, int32_t w, int32_t h) {
+    if (!path || !rgb || w <= 0 || h <= 0) return RTAMD_ERR_INVALID;
+    return rtamd::write_ppm(path, rgb, w, h) ? RTAMD_OK : RTAMD_ERR_INVALID;
+}
+
+} // extern "C"
