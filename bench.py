@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Benchmark of the render pass: Mrays/s (primary + shadow + reflection) and frame time.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+
+One step = one frame: every launch of Flyscene::raytraceScene's replacement (trace + shade per
+recursion level) over the whole image, scene and output buffers resident in HBM.  With N > 1 (one
+process per GPU, started by torch.distributed.run) the frame is cut into row tiles dealt round-robin to
+the ranks, each rank renders its tiles from its own copy of the scene, and the step ends with the one
+gather of the tiles on rank 0 (RCCL).  The total work per step is fixed, so scaling is "strong".
+
+Rank 0 prints one JSON line.  `roofline` describes the kernel that takes most of the frame; its
+duration comes from HIP events recorded on the render stream around every launch of the timed region,
+its algorithmic work from an instrumented (untimed) frame that counts slab and triangle tests.
+`cpu_baseline` times the CPU oracle (the restatement of the reference algorithm, compiled with the
+reference's Release flags) on a bounded sample of the same frame's rows on this machine's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import raytracer_amd as R  # noqa: E402
+from raytracer_amd import _lib as L  # noqa: E402
+from raytracer_amd import tiles, workloads  # noqa: E402
+
+# Peaks from the MI355X microarchitecture guide: FP32 vector 157.3 TFLOP/s (256 CU x 4 SIMD x 32 lanes x
+# packed FMA x 2.4 GHz), HBM3E 8 TB/s.
+PEAK_FP32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+# Algorithmic work per test: the reference's operation counts (one ray/AABB slab test,
+# src/boundingBox.h:257-286: 6 sub, 6 div, 3 swap-compares, 10 min/max, 2 compares = 27; plane distance,
+# src/flyscene.cpp:758-760: 14; hit point + three edge functions, :771-780: 69; Phong per light ~150)
+# and bytes (one AABB 32 B, plane n,D 16 B, vertex ids + vertices 48 B).
+FLOPS_BOX, FLOPS_PLANE, FLOPS_EDGE, FLOPS_SHADE = 27, 14, 69, 150
+BYTES_BOX, BYTES_PLANE, BYTES_EDGE = 32, 16, 48
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=None, help="default: bunny_1080p (1 GPU) / field_4k (several GPUs)")
+    ap.add_argument("--row-tile", type=int, default=16)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample; 0 = skip")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events in the timed region")
+    return ap.parse_args()
+
+
+def cpu_baseline(w, cam, budget_s):
+    """Time the CPU oracle (reference algorithm, reference Release flags) on every k-th row."""
+    from oracle.oracle_py import Camera, OracleScene  # test infrastructure; CPU leg only
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    arrays = workloads.mesh_arrays(w)
+    lights = [tuple(l) + (1.0, 1.0, 1.0) for l in w["lights"]]
+    orc = OracleScene(arrays=arrays, lights=lights, hard_shadow=True, soft_points=w["soft_points"], fast=True)
+    oc = Camera()
+    oc.origin[:] = list(cam.origin)
+    oc.inv_view[:] = list(cam.inv_view)
+    oc.viewport[:] = list(cam.viewport)
+    oc.aspect_ratio, oc.fovy = cam.aspect_ratio, cam.fovy
+    W, H = w["width"], w["height"]
+    kw = dict(max_reflections=w["max_reflections"], num_threads=threads)
+    # calibrate on every 64th row, then pick the stride that fills the budget
+    probe = orc.render(W, H, camera=oc, planes=False, row_offset=H // 128, row_step=64, **kw)["counters"]
+    rate = probe.rays / max(probe.seconds, 1e-9)
+    full_rays_est = probe.rays * 64.0
+    step = max(1, int(np.ceil(full_rays_est / max(rate * budget_s, 1.0))))
+    res = orc.render(W, H, camera=oc, planes=False, row_offset=0, row_step=step, **kw)["counters"]
+    orc.close()
+    return {
+        "value": round(res.rays / res.seconds / 1e6, 4),
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "every %d-th image row of the same frame (%d rays, %.1f s), oracle built -O3 -ffast-math -march=x86-64-v3, "
+                  "rows interleaved over %d threads as the reference does" % (step, res.rays, res.seconds, threads),
+        "box_tests_per_ray": round(res.box_tests / max(res.rays, 1), 1),
+        "tri_tests_per_ray": round(res.tri_plane / max(res.rays, 1), 1),
+    }
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be started with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        a.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    name = a.workload or ("bunny_1080p" if world == 1 else "field_4k")
+    w = workloads.get(name)
+    t0 = time.time()
+    fly, params, cam = workloads.make_flyscene(w)
+    info = fly.info()
+    init_s = time.time() - t0
+    W, H = w["width"], w["height"]
+
+    base = fly.params_copy(row_tile=a.row_tile)
+    mine = tiles.part_params(base, world, rank)
+    rows = fly.local_rows(mine)
+    rgb = torch.zeros((max(rows, 1), W, 3), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def frame(p):
+        fly.render_device(rgb, params=p, camera=cam, stream=stream)
+        if world > 1:
+            return tiles.gather_rows(rgb[:rows], p, dst=0)
+        return rgb
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- instrumented frame (untimed): algorithmic work of each kernel
+    counted = tiles.part_params(base, world, rank)
+    counted.flags = L.FLAG_COUNT_WORK
+    frame(counted)
+    torch.cuda.synchronize(dev)
+    work = fly.stats()
+
+    timed = tiles.part_params(base, world, rank)
+    timed.flags = 0 if a.no_kernel_events else L.FLAG_TIME_KERNELS
+    for _ in range(a.warmup):
+        frame(timed)
+    sync()
+    fly.stats()  # drop the warm-up's events
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        frame(timed)
+    sync()
+    elapsed = time.perf_counter() - t0
+    st = fly.stats()
+
+    # ---- reduce over ranks: slowest rank's time, all ranks' rays
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rays = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_bounce], dtype=torch.float64, device=dev)
+    kern = torch.tensor([st.ms_trace, st.ms_shade, st.launches_trace, st.launches_shade], dtype=torch.float64, device=dev)
+    wk = torch.tensor([work.box_tests[0], work.tri_plane[0], work.tri_edge[0], work.box_tests[1], work.tri_plane[1], work.tri_edge[1],
+                       work.hits], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        dist.all_reduce(wk, op=dist.ReduceOp.SUM)
+        kmax = kern.clone()
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+    else:
+        kmax = kern
+    elapsed = float(t_el.item())
+    rays_frame = float(rays.sum().item())
+    ms_per_step = elapsed / a.steps * 1e3
+    value = rays_frame * a.steps / elapsed / 1e6
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s (primary+shadow+reflection)",
+            "value": round(value, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic" if w["scene"] != "bunny" else "reference scene (bunny.ply converted to OBJ), default camera",
+            "config": {
+                "workload": name, "width": W, "height": H, "triangles": int(info.num_faces), "lights": len(w["lights"]),
+                "samples_per_light": 1 + w["soft_points"], "max_reflections": w["max_reflections"],
+                "rays_per_frame": {"primary": int(rays[0].item()), "shadow": int(rays[1].item()), "bounce": int(rays[2].item())},
+                "parallelism": "row tiles of %d rows round-robin over %d GPU(s), one gather" % (a.row_tile, world),
+                "bvh": {"nodes": int(info.num_nodes), "leaves": int(info.num_leaves), "depth": int(info.depth),
+                        "build_ms": round(float(info.build_ms), 1), "device_MB": round(info.device_bytes / 1e6, 2)},
+                "scene_init_s": round(init_s, 2),
+            },
+        }
+        # ---- roofline of the dominant kernel (slowest rank's event times; work summed over ranks / ranks)
+        if not a.no_kernel_events and kmax[2].item() > 0 and kmax[3].item() > 0:
+            ms_trace = kmax[0].item() / kmax[2].item()
+            ms_shade = kmax[1].item() / kmax[3].item()
+            launches_per_frame = (kmax[2].item() / a.steps, kmax[3].item() / a.steps)
+            wl = wk.cpu().numpy() / world  # per-GPU share of one frame
+            flops = [wl[0] * FLOPS_BOX + wl[1] * FLOPS_PLANE + wl[2] * FLOPS_EDGE,
+                     wl[3] * FLOPS_BOX + wl[4] * FLOPS_PLANE + wl[5] * FLOPS_EDGE + wl[6] * FLOPS_SHADE * len(w["lights"])]
+            byts = [wl[0] * BYTES_BOX + wl[1] * BYTES_PLANE + wl[2] * BYTES_EDGE,
+                    wl[3] * BYTES_BOX + wl[4] * BYTES_PLANE + wl[5] * BYTES_EDGE]
+            k = 0 if kmax[0].item() >= kmax[1].item() else 1
+            kname = ("trace_kernel", "shade_kernel")[k]
+            per_launch_ms = (ms_trace, ms_shade)[k]
+            flops_launch = flops[k] / launches_per_frame[k]
+            bytes_launch = byts[k] / launches_per_frame[k]
+            ach = flops_launch / (per_launch_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": kname, "bound": "valu", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                               "avg_launch_ms": round(per_launch_ms, 4), "launches_per_frame": launches_per_frame[k],
+                               "share_of_frame": round(kmax[k].item() / (kmax[0].item() + kmax[1].item()), 3)}
+            ach_b = bytes_launch / (per_launch_ms * 1e-3) / 1e9
+            out["roofline_hbm"] = {"kernel": kname, "bound": "hbm", "achieved": round(ach_b, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": round(ach_b / PEAK_HBM_GBS, 4), "traffic": None,
+                                   "note": "algorithmic bytes are served by L2 / Infinity Cache; the scene is %.1f MB" % (info.device_bytes / 1e6)}
+            out["kernels"] = {"trace_ms_per_frame": round(kmax[0].item() / a.steps, 4), "shade_ms_per_frame": round(kmax[1].item() / a.steps, 4),
+                              "tests_per_ray": {"box": round((wk[0].item() + wk[3].item()) / rays_frame, 2),
+                                                "tri_plane": round((wk[1].item() + wk[4].item()) / rays_frame, 2),
+                                                "tri_edge": round((wk[2].item() + wk[5].item()) / rays_frame, 2)}}
+        if world == 1 and a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(w, cam, a.cpu_seconds)
+            out["gpu_over_cpu"] = round(value / max(out["cpu_baseline"]["value"], 1e-9), 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -110,21 +110,25 @@ typedef struct {
 } rtamd_render_params;
 
 typedef struct {
+    /* Counters of the most recent frame. */
     uint64_t rays_primary; /* one per pixel sub-sample                                            */
     uint64_t rays_shadow;  /* num_lights*samples_per_light per hit (src/flyscene.cpp:880-887)     */
     uint64_t rays_bounce;  /* reflection rays (src/flyscene.cpp:636)                              */
     uint64_t hits;         /* closest-hit queries that found a surface                            */
-    /* RTAMD_FLAG_COUNT_WORK only: */
-    uint64_t box_tests;    /* ray/AABB slab tests                                                 */
-    uint64_t tri_plane;    /* plane-distance evaluations                                          */
-    uint64_t tri_edge;     /* faces that reached the edge tests                                   */
-    /* RTAMD_FLAG_TIME_KERNELS only (milliseconds, summed over launches): */
+    /* RTAMD_FLAG_COUNT_WORK only, most recent frame; [0] = closest-hit kernel (primary + bounce
+     * rays), [1] = shading kernel (shadow rays): */
+    uint64_t box_tests[2]; /* ray/AABB slab tests                                                 */
+    uint64_t tri_plane[2]; /* plane-distance evaluations                                          */
+    uint64_t tri_edge[2];  /* faces that reached the edge tests                                   */
+    /* RTAMD_FLAG_TIME_KERNELS only: HIP-event durations in milliseconds, summed over every launch
+     * and frame enqueued since the previous rtamd_render_stats call: */
     float ms_trace;
     float ms_shade;
-    float ms_total;
+    float ms_frames;       /* first launch to last launch of each frame, summed                   */
     int32_t launches_trace;
     int32_t launches_shade;
-    int32_t reserved[3];
+    int32_t frames;
+    int32_t reserved[2];
 } rtamd_stats;
 
 typedef struct {
@@ -152,6 +156,13 @@ void rtamd_render_params_default(rtamd_render_params *p, int32_t width, int32_t 
 int rtamd_scene_create(const rtamd_scene_desc *desc, const rtamd_build_params *build, rtamd_scene **out);
 int rtamd_scene_destroy(rtamd_scene *scene);
 int rtamd_scene_get_info(const rtamd_scene *scene, rtamd_scene_info *info);
+
+/* Host only (no device needed): rank[f] = position of face f in the order in which the reference's
+ * triangleIntersection meets the faces (leaves of boundingBox::splitBox in lower/upper preorder,
+ * src/boundingBox.h:69-194,295-307; faces in leaf order, src/flyscene.cpp:750-751).  The kernels use
+ * it to reproduce the reference's rule for equal hit distances: the face met later wins
+ * (src/flyscene.cpp:760).  rank = desc->num_faces ints. */
+int rtamd_reference_face_rank(const rtamd_scene_desc *desc, int32_t *rank);
 
 /* Number of image rows part `p->part` renders, and the image row of local row `local_row`. */
 int32_t rtamd_local_rows(const rtamd_render_params *p);

@@ -57,9 +57,9 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [
         ("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_bounce", C.c_uint64), ("hits", C.c_uint64),
-        ("box_tests", C.c_uint64), ("tri_plane", C.c_uint64), ("tri_edge", C.c_uint64),
-        ("ms_trace", C.c_float), ("ms_shade", C.c_float), ("ms_total", C.c_float),
-        ("launches_trace", C.c_int32), ("launches_shade", C.c_int32), ("reserved", C.c_int32 * 3),
+        ("box_tests", C.c_uint64 * 2), ("tri_plane", C.c_uint64 * 2), ("tri_edge", C.c_uint64 * 2),
+        ("ms_trace", C.c_float), ("ms_shade", C.c_float), ("ms_frames", C.c_float),
+        ("launches_trace", C.c_int32), ("launches_shade", C.c_int32), ("frames", C.c_int32), ("reserved", C.c_int32 * 2),
     ]
 
     @property
@@ -67,7 +67,13 @@ class Stats(C.Structure):
         return self.rays_primary + self.rays_shadow + self.rays_bounce
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        out = {}
+        for k, _ in self._fields_:
+            if k == "reserved":
+                continue
+            v = getattr(self, k)
+            out[k] = list(v) if hasattr(v, "__len__") else v
+        return out
 
 
 class SceneInfo(C.Structure):
@@ -90,6 +96,7 @@ SYMBOLS = {
     "rtamd_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.POINTER(BuildParams), C.POINTER(_P)]),
     "rtamd_scene_destroy": (C.c_int, [_P]),
     "rtamd_scene_get_info": (C.c_int, [_P, C.POINTER(SceneInfo)]),
+    "rtamd_reference_face_rank": (C.c_int, [C.POINTER(SceneDesc), _ip]),
     "rtamd_local_rows": (C.c_int32, [C.POINTER(RenderParams)]),
     "rtamd_global_row": (C.c_int32, [C.POINTER(RenderParams), C.c_int32]),
     "rtamd_render": (C.c_int, [_P, C.POINTER(Camera), C.POINTER(RenderParams), _fp, _ip, C.POINTER(Stats)]),
@@ -123,6 +130,34 @@ SYMBOLS = {
 }
 
 _lib = None
+HIP_RUNTIME = None
+
+
+def _load_hip_runtime():
+    """librtamd.so carries no DT_NEEDED entry for the HIP runtime: the process must hold exactly one copy of
+    libamdhip64 and it has to be the one PyTorch uses, because device buffers, streams and RCCL
+    communicators come from torch.  PyTorch's ROCm wheels bundle their own copy (loaded RTLD_LOCAL), so it
+    is re-opened here with RTLD_GLOBAL, which makes its hip* symbols resolve for the library loaded next.
+    Without torch the system runtime under /opt/rocm is used."""
+    global HIP_RUNTIME
+    candidates = []
+    try:
+        import torch
+
+        candidates.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except ImportError:
+        pass
+    candidates += [os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "libamdhip64.so"), "libamdhip64.so"]
+    for path in candidates:
+        if os.path.isabs(path) and not os.path.exists(path):
+            continue
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+            HIP_RUNTIME = path
+            return
+        except OSError:
+            continue
+    raise ImportError("no HIP runtime (libamdhip64.so) could be loaded; tried %s" % ", ".join(candidates))
 
 
 def lib():
@@ -132,6 +167,7 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s not found: build it with `make -C raytracer_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    _load_hip_runtime()
     handle = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(handle, name)  # AttributeError if the symbol is not exported

@@ -77,9 +77,9 @@ struct rtamd_scene {
     int last_stages = 0, last_depths = 0;
     uint64_t last_primary = 0;
     hipStream_t last_stream = nullptr;
+    // HIP-event pairs of every launch (kind 0/1/2) and frame (kind 3) since the last stats call
     std::vector<TimedLaunch> events;
     size_t events_used = 0;
-    hipEvent_t frame_start = nullptr, frame_stop = nullptr;
 };
 
 namespace {
@@ -300,6 +300,20 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     return RTAMD_OK;
 }
 
+int rtamd_reference_face_rank(const rtamd_scene_desc *d, int32_t *rank_out) {
+    if (!d || !rank_out) return fail(RTAMD_ERR_INVALID, "null scene description or output");
+    if (d->num_faces < 0 || d->num_vertices < 0) return fail(RTAMD_ERR_INVALID, "negative count in scene description");
+    if (d->num_faces > 0 && (!d->vertices || !d->face_vertex_ids)) return fail(RTAMD_ERR_INVALID, "null mesh array");
+    for (int64_t i = 0; i < 3 * (int64_t)d->num_faces; ++i)
+        if (d->face_vertex_ids[i] < 0 || d->face_vertex_ids[i] >= d->num_vertices)
+            return fail(RTAMD_ERR_INVALID, "face %lld references vertex %d of %d", (long long)(i / 3), d->face_vertex_ids[i], d->num_vertices);
+    MeshView mesh{d->vertices, d->num_vertices, d->face_vertex_ids, d->face_normals, d->face_origin_distance, d->num_faces};
+    std::vector<int32_t> rank;
+    reference_face_rank(mesh, rank);
+    std::memcpy(rank_out, rank.data(), rank.size() * sizeof(int32_t));
+    return RTAMD_OK;
+}
+
 int rtamd_scene_destroy(rtamd_scene *s) {
     if (!s) return RTAMD_OK;
     void *bufs[] = {s->d_nodes, s->d_tris, s->d_shade, s->d_materials, s->d_light_pos, s->d_samples, s->d_spheres, s->ws_block, s->d_rgb, s->d_face};
@@ -309,8 +323,6 @@ int rtamd_scene_destroy(rtamd_scene *s) {
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
     }
-    if (s->frame_start) (void)hipEventDestroy(s->frame_start);
-    if (s->frame_stop) (void)hipEventDestroy(s->frame_stop);
     delete s;
     return RTAMD_OK;
 }
@@ -359,7 +371,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
 
     const bool count = (p->flags & RTAMD_FLAG_COUNT_WORK) != 0;
     const bool timed = (p->flags & RTAMD_FLAG_TIME_KERNELS) != 0;
-    s->events_used = 0;
+    size_t open_slot = 0;
     auto begin = [&](int kind) -> int {
         if (!timed) return RTAMD_OK;
         if (s->events_used == s->events.size()) {
@@ -369,22 +381,20 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
             HIP_TRY(hipEventCreate(&t.stop));
             s->events.push_back(t);
         }
-        s->events[s->events_used].kind = kind;
-        HIP_TRY(hipEventRecord(s->events[s->events_used].start, stream));
+        open_slot = s->events_used++;
+        s->events[open_slot].kind = kind;
+        HIP_TRY(hipEventRecord(s->events[open_slot].start, stream));
         return RTAMD_OK;
     };
     auto end = [&]() -> int {
         if (!timed) return RTAMD_OK;
-        HIP_TRY(hipEventRecord(s->events[s->events_used].stop, stream));
-        ++s->events_used;
+        HIP_TRY(hipEventRecord(s->events[open_slot].stop, stream));
         return RTAMD_OK;
     };
+    size_t frame_slot = 0;
     if (timed) {
-        if (!s->frame_start) {
-            HIP_TRY(hipEventCreate(&s->frame_start));
-            HIP_TRY(hipEventCreate(&s->frame_stop));
-        }
-        HIP_TRY(hipEventRecord(s->frame_start, stream));
+        if ((rc = begin(3)) != RTAMD_OK) return rc;
+        frame_slot = open_slot;
     }
 
     HIP_TRY(hipMemsetAsync(s->ws_block, 0, 4096, stream));
@@ -408,7 +418,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
         launch_scale(rgb, pixels * 3, (float)(S * S), stream);
         if ((rc = end()) != RTAMD_OK) return rc;
     }
-    if (timed) HIP_TRY(hipEventRecord(s->frame_stop, stream));
+    if (timed) HIP_TRY(hipEventRecord(s->events[frame_slot].stop, stream));
     HIP_TRY(hipGetLastError());
 
     s->last = *p;
@@ -426,9 +436,9 @@ int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
     if (!s->have_frame) return RTAMD_OK;
     HIP_TRY(hipStreamSynchronize(s->last_stream));
     std::vector<StageCounters> sc((size_t)kMaxStages);
-    WorkCounters wc;
+    WorkCounters wc[2];
     HIP_TRY(hipMemcpy(sc.data(), s->ws.stage, sizeof(StageCounters) * kMaxStages, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&wc, s->ws.work, sizeof wc, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(wc, s->ws.work, sizeof wc, hipMemcpyDeviceToHost));
     st->rays_primary = s->last_primary;
     const uint64_t per_hit = (uint64_t)s->ds.num_lights * (uint64_t)s->ds.spl;
     for (int i = 0; i < s->last_stages; ++i) {
@@ -436,18 +446,19 @@ int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
         st->rays_shadow += (uint64_t)sc[i].hits * per_hit;
         st->rays_bounce += (uint64_t)sc[i].next;
     }
-    st->box_tests = wc.box_tests;
-    st->tri_plane = wc.tri_plane;
-    st->tri_edge = wc.tri_edge;
-    if ((s->last.flags & RTAMD_FLAG_TIME_KERNELS) && s->frame_start) {
-        for (size_t i = 0; i < s->events_used; ++i) {
-            float ms = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&ms, s->events[i].start, s->events[i].stop));
-            if (s->events[i].kind == 0) st->ms_trace += ms, ++st->launches_trace;
-            if (s->events[i].kind == 1) st->ms_shade += ms, ++st->launches_shade;
-        }
-        HIP_TRY(hipEventElapsedTime(&st->ms_total, s->frame_start, s->frame_stop));
+    for (int k = 0; k < 2; ++k) {
+        st->box_tests[k] = wc[k].box_tests;
+        st->tri_plane[k] = wc[k].tri_plane;
+        st->tri_edge[k] = wc[k].tri_edge;
     }
+    for (size_t i = 0; i < s->events_used; ++i) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->events[i].start, s->events[i].stop));
+        if (s->events[i].kind == 0) st->ms_trace += ms, ++st->launches_trace;
+        if (s->events[i].kind == 1) st->ms_shade += ms, ++st->launches_shade;
+        if (s->events[i].kind == 3) st->ms_frames += ms, ++st->frames;
+    }
+    s->events_used = 0;
     return RTAMD_OK;
 }
 

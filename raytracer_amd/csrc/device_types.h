@@ -56,7 +56,7 @@ struct Workspace {
     // ray queues, ping-pong; 10 planes of `capacity` each: o.xyz, d.xyz, throughput.rgb, pixel(bits)
     float *queue[2];
     StageCounters *stage; // kMaxStages
-    WorkCounters *work;
+    WorkCounters *work; // [0] closest-hit kernel, [1] shading kernel (shadow rays)
 };
 
 } // namespace rtamd

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(kShadeWaves * 64) void shade_kernel(DeviceScene sc,
         const unsigned long long clear = __ballot(valid && !occluded);
         if (lane == 0) s_mask[j] = clear;
     }
-    if (COUNT) flush_work(wk, ws.work);
+    if (COUNT) flush_work(wk, ws.work + 1);
     __syncthreads();
     if (wave != 0 || !valid) return;
 

@@ -1,0 +1,103 @@
+"""Host side of the C ABI (OBJ/MTL loader, model matrix, precomputeData, precomputeLights, replay of
+splitBox's face order) against the CPU oracle, bit for bit.  Two independent implementations of the
+reference's initialisation (src/flyscene.cpp:18-250, utils/objimporter.hpp, utils/mtlIO.hpp) must
+produce identical arrays.  No GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import scene_path
+from oracle.oracle_py import OracleScene
+
+import raytracer_amd as R
+from raytracer_amd import _lib as L
+
+SCENES = ["reflect_test", "reflect_test_2", "shadowmodel", "NthTest", "glass", "toy", "toy_on_plane", "dodgeColorTest", "bunny"]
+KEYS = ["raw_vertices", "raw_normals", "vertices", "normals", "face_vertex_ids", "face_normals", "face_origin_distance",
+        "face_material_ids", "materials", "light_samples", "model_matrix"]
+
+
+def same_bits(a, b):
+    a, b = np.ascontiguousarray(a).reshape(-1), np.ascontiguousarray(b).reshape(-1)
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_flattened_scene_is_bit_identical(name):
+    fly = R.Flyscene(model=scene_path(name), output="").initialize(64, 64, upload=False)
+    got = fly.arrays()
+    ref = OracleScene(scene_path(name)).arrays()
+    for k in KEYS:
+        assert same_bits(got[k], ref[k]), "%s: %s differs" % (name, k)
+
+
+def test_face_count_and_order_follow_the_file():
+    a = R.Flyscene(model=scene_path("toy"), output="").initialize(8, 8, upload=False).arrays()
+    assert a["face_vertex_ids"].shape == (12134, 3) and a["vertices"].shape == (6069, 3)
+    # first record of toy.obj: f 228//228 3//3 242//242
+    assert a["face_vertex_ids"][0].tolist() == [227, 2, 241]
+    # unit cube: largest extent exactly 1 up to rounding, centred
+    ext = a["vertices"].max(0) - a["vertices"].min(0)
+    assert abs(ext.max() - 1.0) < 1e-6 and np.abs(a["vertices"].max(0) + a["vertices"].min(0)).max() < 1e-6
+
+
+def test_light_samples_follow_precompute_lights():
+    fly = R.Flyscene(model=scene_path("glass"), lights=[(-1, 1, 1), (0.5, 2.0, -1.0)], output="").initialize(8, 8, upload=False)
+    s = fly.arrays()["light_samples"].reshape(2, 13, 3)
+    assert s[0, 0].tolist() == [-1.0, 1.0, 1.0] and s[1, 0].tolist() == [0.5, 2.0, -1.0]
+    r = np.linalg.norm(s[:, 1:] - s[:, :1], axis=-1)
+    assert np.allclose(r, 0.3, atol=1e-6)  # SOFTSHADOWRADIUS
+    ref = OracleScene(scene_path("glass"), lights=[(-1, 1, 1, 1, 1, 1), (0.5, 2.0, -1.0, 1, 1, 1)]).arrays()["light_samples"]
+    assert same_bits(s, ref)
+    hard = R.Flyscene(model=scene_path("glass"), soft_points=0, output="").initialize(8, 8, upload=False).arrays()["light_samples"]
+    assert hard.shape == (1, 3)
+
+
+def _desc(a):
+    d = L.SceneDesc()
+    keep = [np.ascontiguousarray(a["vertices"]), np.ascontiguousarray(a["normals"]), np.ascontiguousarray(a["face_vertex_ids"]),
+            np.ascontiguousarray(a["face_normals"]), np.ascontiguousarray(a["face_origin_distance"]),
+            np.ascontiguousarray(a["face_material_ids"])]
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    d.vertices, d.normals = keep[0].ctypes.data_as(fp), keep[1].ctypes.data_as(fp)
+    d.num_vertices = len(keep[0])
+    d.face_vertex_ids = keep[2].ctypes.data_as(ip)
+    d.face_normals, d.face_origin_distance = keep[3].ctypes.data_as(fp), keep[4].ctypes.data_as(fp)
+    d.face_material_ids = keep[5].ctypes.data_as(ip)
+    d.num_faces = len(keep[2])
+    return d, keep
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_reference_face_rank_matches_split_box_replay(name):
+    orc = OracleScene(scene_path(name))
+    a = orc.arrays()
+    d, keep = _desc(a)
+    rank = np.full(len(a["face_vertex_ids"]), -1, np.int32)
+    L.check(L.lib().rtamd_reference_face_rank(C.byref(d), rank.ctypes.data_as(C.POINTER(C.c_int32))), "rank")
+    assert sorted(rank.tolist()) == list(range(len(rank)))
+    assert np.array_equal(rank, orc.bvh_face_order())
+
+
+def test_arrays_entry_point_matches_obj_path():
+    obj = R.Flyscene(model=scene_path("toy"), output="").initialize(8, 8, upload=False).arrays()
+    mats = [dict(ka=m[0:3], kd=m[3:6], ks=m[6:9], shininess=m[9]) for m in obj["materials"]]
+    arr = R.Flyscene(arrays=(obj["raw_vertices"], obj["raw_normals"], obj["face_vertex_ids"], obj["face_material_ids"], mats),
+                     output="").initialize(8, 8, upload=False).arrays()
+    for k in KEYS:
+        assert same_bits(obj[k], arr[k]), k
+    # without normals they are recomputed from the faces (objimporter.hpp:81-106), as in the oracle
+    arr2 = R.Flyscene(arrays=(obj["raw_vertices"], None, obj["face_vertex_ids"], obj["face_material_ids"], mats),
+                      output="").initialize(8, 8, upload=False).arrays()
+    ref2 = OracleScene(arrays=(obj["raw_vertices"], None, obj["face_vertex_ids"], obj["face_material_ids"], mats)).arrays()
+    assert same_bits(arr2["normals"], ref2["normals"]) and not same_bits(arr2["normals"], obj["normals"])
+
+
+def test_camera_mirror():
+    fly = R.Flyscene(model=scene_path("glass"), output="").initialize(640, 480, upload=False)
+    cam = fly.getCamera()
+    assert list(cam.origin) == [0.0, 0.0, 2.0] and cam.aspect_ratio == np.float32(640) / np.float32(480)
+    fly.camera_translate(0.0, 0.0, 4.0)  # dz * speed(0.05) towards the scene
+    cam = fly.getCamera()
+    assert np.allclose(list(cam.origin), [0.0, 0.0, 1.8], atol=1e-6)

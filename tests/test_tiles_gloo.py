@@ -1,0 +1,74 @@
+"""Row-tile partition + gather across ranks (the N > 1 path of bench.py) with world_size 2 and 3 on the
+gloo backend: every rank fills its packed rows with a function of the IMAGE row, rank 0 must assemble
+the full image.  No GPU: only the partition arithmetic of the C ABI and the collective are exercised."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import raytracer_amd as R
+from raytracer_amd import _lib as L
+from raytracer_amd import tiles
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, width, height, tile, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        base = R.default_params(width, height, row_tile=tile)
+        mine = tiles.part_params(base, world, rank)
+        lib = L.lib()
+        rows = lib.rtamd_local_rows(C.byref(mine))
+        local = torch.zeros((rows, width, 3), dtype=torch.float32)
+        for lr in range(rows):
+            y = lib.rtamd_global_row(C.byref(mine), lr)
+            local[lr, :, 0] = y
+            local[lr, :, 1] = torch.arange(width, dtype=torch.float32)
+            local[lr, :, 2] = rank
+        img = tiles.gather_rows(local, mine, dst=0)
+        if rank == 0:
+            q.put(img.numpy())
+        else:
+            assert img is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,width,height,tile", [(2, 16, 40, 8), (2, 8, 37, 16), (3, 8, 50, 4)])
+def test_gather_assembles_the_image(world, width, height, tile):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, width, height, tile, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    img = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert img.shape == (height, width, 3)
+    ys = np.arange(height, dtype=np.float32)
+    assert np.array_equal(img[:, 0, 0], ys)
+    assert np.array_equal(img[:, :, 1], np.tile(np.arange(width, dtype=np.float32), (height, 1)))
+    assert np.array_equal(img[:, 0, 2], ((ys // tile) % world).astype(np.float32))
+
+
+def test_single_process_path_is_identity():
+    p = R.default_params(4, 6)
+    local = torch.arange(6 * 4 * 3, dtype=torch.float32).reshape(6, 4, 3)
+    assert torch.equal(tiles.gather_rows(local, p), local)
+    idx = tiles.row_permutation(R.default_params(4, 10, row_tile=2), 3)
+    assert sorted(idx.tolist()) == list(range(10))
