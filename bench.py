@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None, help="default: bunny_1080p (1 GPU) / field_4k (several GPUs)")
     ap.add_argument("--row-tile", type=int, default=16)
+    ap.add_argument("--max-leaf", type=int, default=0, help="BVH: faces per leaf (0 = library default)")
+    ap.add_argument("--sah-bins", type=int, default=0, help="BVH: SAH bins (0 = library default)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample; 0 = skip")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events in the timed region")
     return ap.parse_args()
@@ -111,7 +113,7 @@ def main():
     name = a.workload or ("bunny_1080p" if world == 1 else "field_4k")
     w = workloads.get(name)
     t0 = time.time()
-    fly, params, cam = workloads.make_flyscene(w)
+    fly, params, cam = workloads.make_flyscene(w, max_leaf_faces=a.max_leaf, sah_bins=a.sah_bins)
     info = fly.info()
     init_s = time.time() - t0
     W, H = w["width"], w["height"]
@@ -156,7 +158,8 @@ def main():
     # ---- reduce over ranks: slowest rank's time, all ranks' rays
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     rays = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_bounce], dtype=torch.float64, device=dev)
-    kern = torch.tensor([st.ms_trace, st.ms_shade, st.launches_trace, st.launches_shade], dtype=torch.float64, device=dev)
+    kern = torch.tensor([st.ms_trace, st.ms_shadow, st.launches_trace, st.launches_shadow, st.ms_compact, st.ms_shade, st.ms_frames],
+                        dtype=torch.float64, device=dev)
     wk = torch.tensor([work.box_tests[0], work.tri_plane[0], work.tri_edge[0], work.box_tests[1], work.tri_plane[1], work.tri_edge[1],
                        work.hits], dtype=torch.float64, device=dev)
     if world > 1:
@@ -199,28 +202,30 @@ def main():
         # ---- roofline of the dominant kernel (slowest rank's event times; work summed over ranks / ranks)
         if not a.no_kernel_events and kmax[2].item() > 0 and kmax[3].item() > 0:
             ms_trace = kmax[0].item() / kmax[2].item()
-            ms_shade = kmax[1].item() / kmax[3].item()
+            ms_shadow = kmax[1].item() / kmax[3].item()
             launches_per_frame = (kmax[2].item() / a.steps, kmax[3].item() / a.steps)
             wl = wk.cpu().numpy() / world  # per-GPU share of one frame
             flops = [wl[0] * FLOPS_BOX + wl[1] * FLOPS_PLANE + wl[2] * FLOPS_EDGE,
-                     wl[3] * FLOPS_BOX + wl[4] * FLOPS_PLANE + wl[5] * FLOPS_EDGE + wl[6] * FLOPS_SHADE * len(w["lights"])]
+                     wl[3] * FLOPS_BOX + wl[4] * FLOPS_PLANE + wl[5] * FLOPS_EDGE]
             byts = [wl[0] * BYTES_BOX + wl[1] * BYTES_PLANE + wl[2] * BYTES_EDGE,
                     wl[3] * BYTES_BOX + wl[4] * BYTES_PLANE + wl[5] * BYTES_EDGE]
             k = 0 if kmax[0].item() >= kmax[1].item() else 1
-            kname = ("trace_kernel", "shade_kernel")[k]
-            per_launch_ms = (ms_trace, ms_shade)[k]
+            kname = ("walk_kernel<closest hit>", "walk_kernel<shadow>")[k]
+            per_launch_ms = (ms_trace, ms_shadow)[k]
             flops_launch = flops[k] / launches_per_frame[k]
             bytes_launch = byts[k] / launches_per_frame[k]
             ach = flops_launch / (per_launch_ms * 1e-3) / 1e12
             out["roofline"] = {"kernel": kname, "bound": "valu", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None,
                                "avg_launch_ms": round(per_launch_ms, 4), "launches_per_frame": launches_per_frame[k],
-                               "share_of_frame": round(kmax[k].item() / (kmax[0].item() + kmax[1].item()), 3)}
+                               "share_of_frame": round(kmax[k].item() / max(kmax[6].item(), 1e-9), 3)}
             ach_b = bytes_launch / (per_launch_ms * 1e-3) / 1e9
             out["roofline_hbm"] = {"kernel": kname, "bound": "hbm", "achieved": round(ach_b, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": round(ach_b / PEAK_HBM_GBS, 4), "traffic": None,
                                    "note": "algorithmic bytes are served by L2 / Infinity Cache; the scene is %.1f MB" % (info.device_bytes / 1e6)}
-            out["kernels"] = {"trace_ms_per_frame": round(kmax[0].item() / a.steps, 4), "shade_ms_per_frame": round(kmax[1].item() / a.steps, 4),
+            out["kernels"] = {"trace_ms_per_frame": round(kmax[0].item() / a.steps, 4), "shadow_ms_per_frame": round(kmax[1].item() / a.steps, 4),
+                              "compact_ms_per_frame": round(kmax[4].item() / a.steps, 4), "shade_ms_per_frame": round(kmax[5].item() / a.steps, 4),
+                              "frame_ms_events": round(kmax[6].item() / a.steps, 4),
                               "tests_per_ray": {"box": round((wk[0].item() + wk[3].item()) / rays_frame, 2),
                                                 "tri_plane": round((wk[1].item() + wk[4].item()) / rays_frame, 2),
                                                 "tri_edge": round((wk[2].item() + wk[5].item()) / rays_frame, 2)}}

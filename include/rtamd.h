@@ -116,19 +116,20 @@ typedef struct {
     uint64_t rays_bounce;  /* reflection rays (src/flyscene.cpp:636)                              */
     uint64_t hits;         /* closest-hit queries that found a surface                            */
     /* RTAMD_FLAG_COUNT_WORK only, most recent frame; [0] = closest-hit kernel (primary + bounce
-     * rays), [1] = shading kernel (shadow rays): */
+     * rays), [1] = shadow-ray kernel: */
     uint64_t box_tests[2]; /* ray/AABB slab tests                                                 */
     uint64_t tri_plane[2]; /* plane-distance evaluations                                          */
     uint64_t tri_edge[2];  /* faces that reached the edge tests                                   */
     /* RTAMD_FLAG_TIME_KERNELS only: HIP-event durations in milliseconds, summed over every launch
      * and frame enqueued since the previous rtamd_render_stats call: */
-    float ms_trace;
-    float ms_shade;
+    float ms_trace;        /* closest-hit traversal kernel                                        */
+    float ms_shadow;       /* shadow-ray traversal kernel                                         */
+    float ms_compact;      /* hit-list compaction kernel                                          */
+    float ms_shade;        /* shading kernel                                                      */
     float ms_frames;       /* first launch to last launch of each frame, summed                   */
     int32_t launches_trace;
-    int32_t launches_shade;
+    int32_t launches_shadow;
     int32_t frames;
-    int32_t reserved[2];
 } rtamd_stats;
 
 typedef struct {

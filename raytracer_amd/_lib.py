@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librtamd.so")
+LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(_HERE, "lib", "librtamd.so")  # RTAMD_LIB: experiment builds
 
 OK, ERR_INVALID, ERR_HIP, ERR_LIMIT, ERR_NO_DEVICE = 0, 1, 2, 3, 4
 FACE_SPHERE, FACE_MISS = -1, -2
@@ -58,8 +58,8 @@ class Stats(C.Structure):
     _fields_ = [
         ("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_bounce", C.c_uint64), ("hits", C.c_uint64),
         ("box_tests", C.c_uint64 * 2), ("tri_plane", C.c_uint64 * 2), ("tri_edge", C.c_uint64 * 2),
-        ("ms_trace", C.c_float), ("ms_shade", C.c_float), ("ms_frames", C.c_float),
-        ("launches_trace", C.c_int32), ("launches_shade", C.c_int32), ("frames", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("ms_trace", C.c_float), ("ms_shadow", C.c_float), ("ms_compact", C.c_float), ("ms_shade", C.c_float),
+        ("ms_frames", C.c_float), ("launches_trace", C.c_int32), ("launches_shadow", C.c_int32), ("frames", C.c_int32),
     ]
 
     @property

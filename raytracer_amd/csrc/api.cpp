@@ -52,13 +52,14 @@ double now_ms() {
 
 struct TimedLaunch {
     hipEvent_t start, stop;
-    int kind; // 0 trace, 1 shade, 2 other
+    int kind; // 0 closest-hit walk, 1 shadow walk, 2 compaction, 3 shading, 4 other, 5 whole frame
 };
 
 } // namespace
 
 struct rtamd_scene {
     int device = -1;
+    int num_cus = 256;
     void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_materials = nullptr;
     void *d_light_pos = nullptr, *d_samples = nullptr, *d_spheres = nullptr;
     DeviceScene ds{};
@@ -93,29 +94,32 @@ int upload(void **dst, const std::vector<T> &src, uint64_t *bytes) {
     return RTAMD_OK;
 }
 
-int ensure_workspace(rtamd_scene *s, size_t pixels) {
-    if (s->ws_block && (size_t)s->ws.capacity >= pixels) return RTAMD_OK;
-    if (pixels > (size_t)0x7fffffff / 4) return fail(RTAMD_ERR_LIMIT, "image part of %zu pixels exceeds the 2^29 pixel limit", pixels);
+// `slots` = ray slots of the local image = whole 8x8 tiles (a multiple of 64).
+int ensure_workspace(rtamd_scene *s, size_t slots) {
+    if (s->ws_block && (size_t)s->ws.capacity >= slots) return RTAMD_OK;
     if (s->ws_block) {
         HIP_TRY(hipFree(s->ws_block));
         s->ws_block = nullptr;
     }
-    // capacity rounded up so that every plane starts 256-byte aligned
-    const size_t cap = (pixels + 63) & ~(size_t)63;
-    const size_t planes = 2 /*slot, tri*/ + 3 /*hit point*/ + 20 /*two queues*/;
+    const size_t cap = (slots + 255) & ~(size_t)255; // every plane starts 1 KiB aligned
+    const size_t nshadow = (size_t)s->ds.num_lights * (size_t)s->ds.spl;
+    const size_t planes = 2 /*slot tri, t*/ + 2 /*hit slot, tri*/ + 3 /*hit point*/ + 20 /*two queues*/;
     const size_t head = 4096; // stage counters + work counters
-    const size_t total = head + planes * cap * 4;
+    const size_t total = head + planes * cap * 4 + nshadow * cap;
     HIP_TRY(hipMalloc(&s->ws_block, total));
     char *base = (char *)s->ws_block;
     s->ws.stage = (StageCounters *)base;
     s->ws.work = (WorkCounters *)(base + 2048);
     static_assert(sizeof(StageCounters) * kMaxStages <= 2048, "counter block too small");
     char *p = base + head;
+    s->ws.slot_tri = (int32_t *)p, p += cap * 4;
+    s->ws.slot_t = (float *)p, p += cap * 4;
     s->ws.hit_slot = (int32_t *)p, p += cap * 4;
     s->ws.hit_tri = (int32_t *)p, p += cap * 4;
     s->ws.hit_p = (float *)p, p += 3 * cap * 4;
     s->ws.queue[0] = (float *)p, p += 10 * cap * 4;
     s->ws.queue[1] = (float *)p, p += 10 * cap * 4;
+    s->ws.clear = (uint8_t *)p, p += nshadow * cap;
     s->ws.capacity = (int32_t)cap;
     return RTAMD_OK;
 }
@@ -220,6 +224,7 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     rtamd_scene *s = new (std::nothrow) rtamd_scene();
     if (!s) return fail(RTAMD_ERR_INVALID, "out of host memory");
     s->device = dev;
+    s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
     // ---- host build
     const double t0 = now_ms();
@@ -351,7 +356,12 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     if (stages > kMaxStages) return fail(RTAMD_ERR_LIMIT, "ssaa^2 * (max_reflections + 1) = %d exceeds %d", stages, kMaxStages);
     s->have_frame = false;
     if (pixels == 0) return RTAMD_OK;
-    rc = ensure_workspace(s, pixels);
+    const int tiles_x = (p->width + 7) / 8, tiles_y = (local_rows + 7) / 8;
+    const size_t slots = (size_t)tiles_x * (size_t)tiles_y * 64;
+    const size_t nshadow = (size_t)s->ds.num_lights * (size_t)s->ds.spl;
+    if (slots * (nshadow ? nshadow : 1) > (size_t)0x7f000000)
+        return fail(RTAMD_ERR_LIMIT, "%zu ray slots x %zu shadow rays per hit exceed the 2^31 work-item limit of one launch", slots, nshadow);
+    rc = ensure_workspace(s, slots);
     if (rc != RTAMD_OK) return rc;
 
     FrameConst fc;
@@ -364,6 +374,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     fc.scale = (float)(1.0 / (double)persp);
     fc.ax = cam->aspect_ratio * fc.scale;
     fc.width = p->width, fc.height = p->height, fc.local_rows = local_rows;
+    fc.tiles_x = tiles_x, fc.tiles_y = tiles_y;
     fc.row_tile = p->row_tile, fc.num_parts = p->num_parts, fc.part = p->part;
     fc.t_eps = p->t_epsilon, fc.refl_thresh = p->reflect_threshold, fc.bounce_off = p->bounce_offset;
     std::memcpy(fc.bg, p->background, sizeof fc.bg);
@@ -393,7 +404,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     };
     size_t frame_slot = 0;
     if (timed) {
-        if ((rc = begin(3)) != RTAMD_OK) return rc;
+        if ((rc = begin(5)) != RTAMD_OK) return rc;
         frame_slot = open_slot;
     }
 
@@ -406,15 +417,23 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
             fc.accumulate = (xs | ys) != 0;
             for (int d = 0; d < depths; ++d, ++stage) {
                 if ((rc = begin(0)) != RTAMD_OK) return rc;
-                launch_trace(d == 0, count, s->ds, fc, s->ws, stage, d & 1, rgb, face_id, t_hit, stream);
+                launch_walk_closest(d == 0, count, s->ds, fc, s->ws, stage, d & 1, stream);
                 if ((rc = end()) != RTAMD_OK) return rc;
-                if ((rc = begin(1)) != RTAMD_OK) return rc;
-                launch_shade(d == 0, count, s->ds, fc, s->ws, stage, d & 1, d + 1 < depths, rgb, stream);
+                if ((rc = begin(2)) != RTAMD_OK) return rc;
+                launch_compact(d == 0, s->ds, fc, s->ws, stage, d & 1, rgb, face_id, t_hit, stream);
+                if ((rc = end()) != RTAMD_OK) return rc;
+                if (nshadow > 0) {
+                    if ((rc = begin(1)) != RTAMD_OK) return rc;
+                    launch_walk_shadow(count, s->ds, fc, s->ws, stage, stream);
+                    if ((rc = end()) != RTAMD_OK) return rc;
+                }
+                if ((rc = begin(3)) != RTAMD_OK) return rc;
+                launch_shade(d == 0, s->ds, fc, s->ws, stage, d & 1, d + 1 < depths, rgb, stream);
                 if ((rc = end()) != RTAMD_OK) return rc;
             }
         }
     if (S > 1) {
-        if ((rc = begin(2)) != RTAMD_OK) return rc;
+        if ((rc = begin(4)) != RTAMD_OK) return rc;
         launch_scale(rgb, pixels * 3, (float)(S * S), stream);
         if ((rc = end()) != RTAMD_OK) return rc;
     }
@@ -455,8 +474,10 @@ int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, s->events[i].start, s->events[i].stop));
         if (s->events[i].kind == 0) st->ms_trace += ms, ++st->launches_trace;
-        if (s->events[i].kind == 1) st->ms_shade += ms, ++st->launches_shade;
-        if (s->events[i].kind == 3) st->ms_frames += ms, ++st->frames;
+        if (s->events[i].kind == 1) st->ms_shadow += ms, ++st->launches_shadow;
+        if (s->events[i].kind == 2) st->ms_compact += ms;
+        if (s->events[i].kind == 3) st->ms_shade += ms;
+        if (s->events[i].kind == 5) st->ms_frames += ms, ++st->frames;
     }
     s->events_used = 0;
     return RTAMD_OK;

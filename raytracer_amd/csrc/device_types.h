@@ -4,9 +4,8 @@
 
 namespace rtamd {
 
-constexpr int kStackEntries = 32;   // per-lane traversal stack in LDS; the builder bounds the tree depth to this
-constexpr int kShadeWaves = 4;      // waves per workgroup of the shading kernel
-constexpr int kMaxShadowRays = 512; // lights * samples_per_light handled by one shading workgroup
+constexpr int kStackEntries = 32;   // per-lane traversal stack (LDS + private memory); the builder bounds the tree depth to this
+constexpr int kMaxShadowRays = 512; // lights * samples_per_light per hit
 constexpr int kMaxStages = 64;      // (ssaa passes) * (max_reflections + 1) counter slots per frame
 
 // Read-only scene in HBM.
@@ -30,33 +29,40 @@ struct FrameConst {
     float scale; // 1 / perspective scale  (camera.hpp:168)
     float sub_x, sub_y; // sub-sample offset of this SSAA pass (src/flyscene.cpp:816-817)
     int32_t width, height, local_rows;
+    int32_t tiles_x, tiles_y; // 8x8-pixel tiles of the local image
     int32_t row_tile, num_parts, part;
     float t_eps, refl_thresh, bounce_off;
     float bg[3], bg_deep[3];
     int32_t accumulate; // 0: first SSAA pass stores the pixel, 1: later passes add to it
 };
 
-// Per-stage counters, zeroed once per frame.
+// Per-stage counters (one stage = one recursion level of one SSAA pass), zeroed once per frame.
 struct StageCounters {
-    int32_t hits;  // entries of the hit list written by the trace kernel
-    int32_t next;  // rays appended to the next queue by the shading kernel
+    int32_t hits;          // entries of the hit list (written by the compaction kernel)
+    int32_t next;          // rays appended to the next queue by the shading kernel
+    int32_t cursor_trace;  // work cursor of the closest-hit kernel
+    int32_t cursor_shadow; // work cursor of the shadow kernel
 };
 
 struct WorkCounters {
     unsigned long long box_tests, tri_plane, tri_edge, pad;
 };
 
-// Work buffers in HBM, sized for `capacity` ray slots (= pixels of the local image).
+// Work buffers in HBM, sized for `capacity` ray slots (= pixels of the local image, padded to whole tiles).
 struct Workspace {
     int32_t capacity;
-    // hit list of the current stage (positions 0..hits-1)
-    int32_t *hit_slot; // ray slot: pixel index (primary) or queue index (bounce)
-    int32_t *hit_tri;  // TriRecord index, or -1 for a sphere
+    // per ray slot, written by the closest-hit kernel
+    int32_t *slot_tri; // TriRecord index, -1 sphere, -2 miss
+    float *slot_t;     // hit distance
+    // hit list of the current stage (positions 0..hits-1), written by the compaction kernel
+    int32_t *hit_slot; // ray slot: tile-ordered pixel (primary) or queue index (bounce)
+    int32_t *hit_tri;
     float *hit_p;      // 3 planes of `capacity`: hit point
+    uint8_t *clear;    // [lights*samples][capacity]: 1 = the shadow ray of that sample is unoccluded
     // ray queues, ping-pong; 10 planes of `capacity` each: o.xyz, d.xyz, throughput.rgb, pixel(bits)
     float *queue[2];
     StageCounters *stage; // kMaxStages
-    WorkCounters *work; // [0] closest-hit kernel, [1] shading kernel (shadow rays)
+    WorkCounters *work;   // [0] closest-hit kernel, [1] shadow kernel
 };
 
 } // namespace rtamd

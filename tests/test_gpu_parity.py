@@ -200,7 +200,7 @@ def test_counted_frame_matches_plain_frame():
     assert np.array_equal(plain["rgb"].view(np.uint32), counted["rgb"].view(np.uint32))
     st = counted["stats"]
     assert st.box_tests[0] > 0 and st.box_tests[1] > 0 and st.tri_plane[0] >= st.tri_edge[0] > 0
-    assert st.launches_trace >= 1 and st.launches_shade >= 1 and st.ms_frames > 0
+    assert st.launches_trace >= 1 and st.launches_shadow >= 1 and st.ms_frames > 0 and st.ms_shade > 0 and st.ms_compact > 0
 
 
 def test_raytrace_scene_writes_the_reference_ppm(tmp_path):

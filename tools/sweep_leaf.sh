@@ -1,0 +1,8 @@
+#!/bin/bash
+# BVH leaf-size sweep (run on the GPU box from the repository root).
+for wl in ${WORKLOADS:-bunny_1000 field_4k}; do
+  for leaf in 1 2 4 8; do
+      out=$(timeout -k 10 120 python3 bench.py --steps 30 --warmup 5 --cpu-seconds 0 --workload $wl --max-leaf $leaf 2>/dev/null | tail -1)
+      echo "$wl leaf=$leaf $(echo "$out" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); k=d["kernels"]; print("Mrays/s %.0f  ms %.3f  trace %.3f shadow %.3f compact %.3f shade %.3f" % (d["value"], d["ms_per_step"], k["trace_ms_per_frame"], k["shadow_ms_per_frame"], k["compact_ms_per_frame"], k["shade_ms_per_frame"]), k["tests_per_ray"], d["config"]["bvh"])')"
+  done
+done

@@ -1,0 +1,10 @@
+#!/bin/bash
+# A/B of the traversal launch shapes (run on the GPU box from the repository root).
+for wl in ${WORKLOADS:-bunny_1000 bunny_1080p field_4k}; do
+  for mode in static dynamic; do
+    for thr in 64 256; do
+      out=$(RTAMD_WALK=$mode RTAMD_WALK_THREADS=$thr timeout -k 10 120 python3 bench.py --steps 30 --warmup 5 --cpu-seconds 0 --workload $wl 2>/dev/null | tail -1)
+      echo "$wl $mode $thr $(echo "$out" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); k=d["kernels"]; print("Mrays/s %.0f  ms %.3f  trace %.3f shadow %.3f compact %.3f shade %.3f" % (d["value"], d["ms_per_step"], k["trace_ms_per_frame"], k["shadow_ms_per_frame"], k["compact_ms_per_frame"], k["shade_ms_per_frame"]))')"
+    done
+  done
+done
