@@ -299,7 +299,8 @@ void build_flat_bvh(const MeshView &mesh, const std::vector<int32_t> &rank, int 
     if (n > 0) root = sb.build(0, n, 0, rb);
     if (n == 0 || root < 0) {
         // The kernels start at inner node 0: wrap a lone leaf (or nothing) in one node whose second
-        // child is an empty box that no ray can enter.
+        // child is a leaf with zero records.  Its inverted box does NOT keep rays out (the slab test
+        // takes min/max of the two bounds), so the kernels skip zero-record leaves themselves.
         BvhNode nd;
         std::memset(&nd, 0, sizeof nd);
         const float inf = INFINITY;

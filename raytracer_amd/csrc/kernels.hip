@@ -153,9 +153,10 @@ __device__ __forceinline__ void flush_work(unsigned a, unsigned b, unsigned c, W
 //             sample POSITION (src/flyscene.cpp:884) from the un-offset hit point; any accepted face ends
 //             the walk.
 // The grid covers the worst case (every slot a ray, every slot a hit); waves beyond the actual count --
-// which lives in device memory -- leave at once, and the hardware dispatcher balances the rest.  Waves
-// whose blockIdx agree modulo 8 run on one XCD and share its L2, so each of those eight families gets a
-// contiguous range of groups (a band of the image): the part of the scene a band touches fits one L2.
+// which lives in device memory -- leave at once, and the hardware dispatcher balances the rest.
+// Consecutive workgroups go to consecutive XCDs, so every XCD sees an interleaved sample of the whole
+// image; giving each XCD a contiguous band instead was measured slower (the bands differ in cost and the
+// static assignment cannot rebalance them).
 // Closest-hit modes write (record index, distance) per slot; the reference's rule for equal distances
 // -- the face met later in ITS visiting order wins (src/flyscene.cpp:760) -- is applied through the
 // per-face rank, which makes the result independent of the order of this walk.
@@ -163,46 +164,75 @@ __device__ __forceinline__ void flush_work(unsigned a, unsigned b, unsigned c, W
 // the host-side builder bounds the tree depth to kStackEntries.
 // ---------------------------------------------------------------------------------------------
 #ifndef RT_LDS_STACK
-#define RT_LDS_STACK 16
+#define RT_LDS_STACK 8
 #endif
 #ifndef RT_WAVES_PER_SIMD
-#define RT_WAVES_PER_SIMD 8
+#define RT_WAVES_PER_SIMD 6
 #endif
-#ifndef RT_XCD_REMAP
-#define RT_XCD_REMAP 0
+#ifndef RT_MIN_GROUP_SHIFT
+#define RT_MIN_GROUP_SHIFT 4
+#endif
+#ifndef RT_LEAF_QUEUE
+#define RT_LEAF_QUEUE 12
+#endif
+#ifndef RT_LEAF_QUEUE_CLOSEST
+#define RT_LEAF_QUEUE_CLOSEST 8
 #endif
 constexpr int kLdsStack = RT_LDS_STACK;
+constexpr int kLeafQueue = RT_LEAF_QUEUE;                // parked leaves per lane, any-hit walks
+constexpr int kLeafQueueClosest = RT_LEAF_QUEUE_CLOSEST; // closest-hit walks: parking delays the pruning
+static_assert(kLeafQueueClosest >= 1 && kLeafQueueClosest <= kLeafQueue, "leaf queue sizes");
+constexpr int kMinGroupShift = RT_MIN_GROUP_SHIFT; // narrowest group: 16 rays
+constexpr int kFullChipWaves = 8192;               // a launch with fewer groups leaves SIMDs of the 256 CUs idle
+
+// Entry `sp` of the traversal stack.  The empty asm keeps the two loads in separate blocks: merged into one
+// load through a selected generic pointer they would become flat accesses.
+__device__ __forceinline__ int stack_read(const int *stack, const int *deep, int sp) {
+    int v;
+    if (sp < kLdsStack) {
+        v = stack[sp * 64];
+    } else {
+        v = deep[sp - kLdsStack];
+        asm volatile("" : "+v"(v));
+    }
+    return v;
+}
 
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int cur_queue, int total_static) {
-    __shared__ int s_stack[kLdsStack * 64];
+    __shared__ int s_stack[(kLdsStack + kLeafQueue) * 64];
     int deep[kStackEntries - kLdsStack > 0 ? kStackEntries - kLdsStack : 1];
     constexpr bool ANY = MODE == kShadow;
     const int lane = (int)threadIdx.x;
     int *const stack = s_stack + lane;
+    int *const leafq = s_stack + kLdsStack * 64 + lane;
+    constexpr int CAP = MODE == kShadow ? kLeafQueue : kLeafQueueClosest;
 
     const int nshadow = sc.num_lights * sc.spl;
-    int total, nhits = 0;
+    int rays, nhits = 0;
     if (MODE == kPrimary) {
-        total = total_static;
+        rays = total_static;
     } else if (MODE == kQueue) {
-        total = ws.stage[stage - 1].next;
+        rays = ws.stage[stage - 1].next;
     } else {
         nhits = ws.stage[stage].hits;
-        total = ((nhits + 63) >> 6) * nshadow * 64;
+        rays = nhits * nshadow;
     }
-    const int ngroups = (total + 63) >> 6;
+    // Lanes per group.  A launch too small to fill the chip with full waves (bounce stages) is bound by the
+    // dependent-load chain of its slowest wave; narrower groups make more, shorter chains out of the same rays.
+    int shift = 6;
+    if (MODE == kQueue) // measured: no gain for shadow rays, whose groups already share origin region and direction
+        while (shift > kMinGroupShift && (rays >> shift) < kFullChipWaves) --shift;
+    const int width = 1 << shift;
+    const int per_sample = MODE == kShadow ? (nhits + width - 1) >> shift : 0; // hit chunks
+    const int ngroups = MODE == kShadow ? per_sample * nshadow : (rays + width - 1) >> shift;
     unsigned w_box = 0, w_plane = 0, w_edge = 0;
 
-    for (int w = (int)blockIdx.x; w < ngroups; w += (int)gridDim.x) {
-        // bijective remap of the wave index: family w % 8 -> contiguous range of groups
-        const int q = ngroups >> 3, rem = ngroups & 7;
-        const int fam = w & 7, idx = w >> 3;
-        const int group = RT_XCD_REMAP ? (fam < rem ? fam * (q + 1) : rem * (q + 1) + (fam - rem) * q) + idx : w;
-        const int item = group * 64 + lane;
+    for (int group = (int)blockIdx.x; group < ngroups; group += (int)gridDim.x) {
+        const int item = (group << shift) + lane;
 
         V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-        bool valid;
+        bool valid = lane < width;
         int out_index;
         if (MODE == kPrimary) {
             int x, row;
@@ -211,7 +241,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
             o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
             if (valid) d = primary_direction(fc, x, row);
         } else if (MODE == kQueue) {
-            valid = item < total;
+            valid = valid && item < rays;
             out_index = item;
             if (valid) {
                 float *qd = ws.queue[cur_queue];
@@ -220,8 +250,8 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
             }
         } else {
             const int chunk = group / nshadow, sample = group - chunk * nshadow;
-            const int hit = chunk * 64 + lane;
-            valid = hit < nhits;
+            const int hit = (chunk << shift) + lane;
+            valid = valid && hit < nhits;
             out_index = sample * ws.capacity + hit;
             if (valid) {
                 o = mk(plane(ws.hit_p, ws.capacity, 0)[hit], plane(ws.hit_p, ws.capacity, 1)[hit], plane(ws.hit_p, ws.capacity, 2)[hit]);
@@ -251,14 +281,30 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
         int best_tri = -2, best_rank = -1;
         // intersects(): spheres first, then triangles, sharing the running maximum (:673-676)
         if (sc.num_spheres > 0 && spheres_hit(sc, o, d, fc.t_eps, tbest)) best_tri = -1;
-        int node = 0, sp = 0;
+        int node = 0, sp = 0, nq = 0;
         if (ANY && best_tri == -1) node = kSentinel; // a sphere already blocks the sample
         // far limit, widened so that equal and last-bit-different distances are still visited
         float tlimit = ANY ? FLT_MAX : tbest * 1.000001f;
 
-        while (node != kSentinel) {
-            // inner nodes: descend until this lane stands on a leaf or has nothing left
-            while (node >= 0 && node != kSentinel) {
+        for (;;) {
+            // Node phase.  A leaf is parked in this lane's leaf queue and the descent goes on, so that the wave
+            // switches between box tests and face tests as rarely as possible; a lane whose queue is full
+            // waits for the others with the leaf still in `node`.
+            while (node != kSentinel) {
+                if (node < 0) {
+                    if ((~node & 15) != 0) { // the builder's placeholder leaf holds no face: never parked
+                        if (nq == CAP) break;
+                        leafq[nq * 64] = node;
+                        ++nq;
+                    }
+                    if (sp == 0) {
+                        node = kSentinel;
+                    } else {
+                        --sp;
+                        node = stack_read(stack, deep, sp);
+                    }
+                    continue;
+                }
                 const float4 nx = sc.nodes[node * 4 + 0];
                 const float4 ny = sc.nodes[node * 4 + 1];
                 const float4 nz = sc.nodes[node * 4 + 2];
@@ -294,17 +340,22 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
                     node = kSentinel;
                 } else {
                     --sp;
-                    node = sp < kLdsStack ? stack[sp * 64] : deep[sp - kLdsStack];
+                    node = stack_read(stack, deep, sp);
                 }
             }
-            if (node == kSentinel) break;
+            if (nq == 0) break; // nothing parked: the walk of this lane is over
 
-            // leaf: exact plane + three-edge test of every face, src/flyscene.cpp:752-789
-            const int ref = ~node;
-            const int first = ref >> 4, count = ref & 15;
+            // Face phase: exact plane + three-edge test of every face of every parked leaf,
+            // src/flyscene.cpp:752-789
             bool blocked = false;
-            for (int k = 0; k < count; ++k) {
-                const int i = first + k;
+            int qi = 0, k = 0;
+            while (qi < nq) {
+                const int ref = ~leafq[qi * 64];
+                const int i = (ref >> 4) + k;
+                if (++k == (ref & 15)) {
+                    k = 0;
+                    ++qi;
+                }
                 const float4 pn = sc.tris[i * 4 + 0];
                 const float4 p0 = sc.tris[i * 4 + 1];
                 const float4 p1 = sc.tris[i * 4 + 2];
@@ -330,14 +381,10 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
                 best_rank = rank;
                 tlimit = t * 1.000001f;
             }
+            nq = 0;
             if (ANY && blocked) {
                 best_tri = 0;
-                node = kSentinel;
-            } else if (sp == 0) {
-                node = kSentinel;
-            } else {
-                --sp;
-                node = sp < kLdsStack ? stack[sp * 64] : deep[sp - kLdsStack];
+                break;
             }
         }
 
