@@ -103,6 +103,38 @@ def cpu_baseline(w, cam, budget_s):
     }
 
 
+def pmc_traffic(workload, kernel_key):
+    """HBM-side bytes per launch of one kernel from the committed counter summary of this workload
+    (profiles/*_pmc_<workload>.txt, written by tools/pmc_passes.sh + tools/pmc_summary.py): FETCH_SIZE and
+    WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests of 16-byte-per-lane loads at
+    64 bytes, hence the factor 2 on the read side."""
+    import glob
+    import re
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_%s.txt" % workload))):
+        best = path
+    if best is None:
+        return None, None
+    fetch = write = None
+    current = None
+    for line in open(best):
+        if not line.startswith(" "):
+            current = line.strip()
+            continue
+        if current != kernel_key:
+            continue
+        m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+mean\s+([0-9.]+)", line)
+        if m:
+            if m.group(1) == "FETCH_SIZE":
+                fetch = float(m.group(2))
+            else:
+                write = float(m.group(2))
+    if fetch is None or write is None:
+        return None, None
+    return (2.0 * fetch + write) * 1024.0, os.path.basename(best)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -228,9 +260,15 @@ def main():
                                "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None,
                                "avg_launch_ms": round(per_launch_ms, 4), "launches_per_frame": launches_per_frame[k],
                                "share_of_frame": round(kmax[k].item() / max(kmax[6].item(), 1e-9), 3)}
+            traffic, traffic_src = pmc_traffic(name, ("walk_kernel<1, false>", "walk_kernel<2, false>")[k] if name != "field_4k" else
+                                               ("walk_kernel<0, false>", "walk_kernel<2, false>")[k])
+            out["roofline"]["traffic"] = None if traffic is None else round(traffic)
+            if traffic is not None:
+                out["roofline"]["traffic_unit"] = "bytes/launch at the L2's memory side, (2*FETCH_SIZE + WRITE_SIZE) KiB, from profiles/" + traffic_src
+                out["roofline"]["algorithmic_bytes_per_launch"] = round(bytes_launch)
             ach_b = bytes_launch / (per_launch_ms * 1e-3) / 1e9
             out["roofline_hbm"] = {"kernel": kname, "bound": "hbm", "achieved": round(ach_b, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": round(ach_b / PEAK_HBM_GBS, 4), "traffic": None,
+                                   "frac": round(ach_b / PEAK_HBM_GBS, 4), "traffic": None if traffic is None else round(traffic),
                                    "note": "algorithmic bytes are served by L2 / Infinity Cache; the scene is %.1f MB" % (info.device_bytes / 1e6)}
             out["kernels"] = {"trace_ms_per_frame": round(kmax[0].item() / a.steps, 4), "shadow_ms_per_frame": round(kmax[1].item() / a.steps, 4),
                               "compact_ms_per_frame": round(kmax[4].item() / a.steps, 4), "shade_ms_per_frame": round(kmax[5].item() / a.steps, 4),
@@ -238,6 +276,26 @@ def main():
                               "tests_per_ray": {"box": round((wk[0].item() + wk[3].item()) / rays_frame, 2),
                                                 "tri_plane": round((wk[1].item() + wk[4].item()) / rays_frame, 2),
                                                 "tri_edge": round((wk[2].item() + wk[5].item()) / rays_frame, 2)}}
+        if world == 1:
+            # the same frame through the blocking host-buffer entry point (upload of nothing, download of
+            # rgb + face ids over PCIe): reported beside `value`, never as `value`
+            plain = tiles.part_params(base, 1, 0)
+            h_rgb = np.zeros((H, W, 3), np.float32)
+            h_fid = np.zeros((H, W), np.int32)
+            h_st = L.Stats()
+            lib = L.lib()
+
+            def host_frame():
+                L.check(lib.rtamd_render(fly.scene, C.byref(cam), C.byref(plain), h_rgb.ctypes.data_as(C.POINTER(C.c_float)),
+                                         h_fid.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(h_st)), "rtamd_render")
+
+            host_frame()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                host_frame()
+            host_ms = (time.perf_counter() - t0) / 5 * 1e3
+            out["host_boundary"] = {"ms_per_frame": round(host_ms, 3), "Mrays_per_s": round(rays_frame / host_ms / 1e3, 1),
+                                    "note": "rtamd_render with host output buffers, PCIe download included"}
         if world == 1 and a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(w, cam, a.cpu_seconds)
             out["gpu_over_cpu"] = round(value / max(out["cpu_baseline"]["value"], 1e-9), 1)
