@@ -78,9 +78,13 @@ struct rtamd_scene {
     int last_stages = 0, last_depths = 0;
     uint64_t last_primary = 0;
     hipStream_t last_stream = nullptr;
-    // HIP-event pairs of every launch (kind 0/1/2) and frame (kind 3) since the last stats call
+    // HIP-event pairs of every launch (kind 0..4) and frame (kind 5) since the last stats call
     std::vector<TimedLaunch> events;
     size_t events_used = 0;
+    // Second stream of a frame with reflections: the closest-hit chain (walk, compact of every depth) runs
+    // here while the caller's stream runs the lighting chain (shadow walk, shade); `sync` orders the two.
+    hipStream_t geometry_stream = nullptr;
+    std::vector<hipEvent_t> sync;
 };
 
 namespace {
@@ -103,7 +107,7 @@ int ensure_workspace(rtamd_scene *s, size_t slots) {
     }
     const size_t cap = (slots + 255) & ~(size_t)255; // every plane starts 1 KiB aligned
     const size_t nshadow = (size_t)s->ds.num_lights * (size_t)s->ds.spl;
-    const size_t planes = 2 /*slot tri, t*/ + 2 /*hit slot, tri*/ + 3 /*hit point*/ + 20 /*two queues*/;
+    const size_t planes = 2 /*slot tri, t*/ + 2 * 6 /*two hit lists: slot, tri, child, point*/ + 30 /*three queues*/;
     const size_t head = 4096; // stage counters + work counters
     const size_t total = head + planes * cap * 4 + nshadow * cap;
     HIP_TRY(hipMalloc(&s->ws_block, total));
@@ -114,11 +118,13 @@ int ensure_workspace(rtamd_scene *s, size_t slots) {
     char *p = base + head;
     s->ws.slot_tri = (int32_t *)p, p += cap * 4;
     s->ws.slot_t = (float *)p, p += cap * 4;
-    s->ws.hit_slot = (int32_t *)p, p += cap * 4;
-    s->ws.hit_tri = (int32_t *)p, p += cap * 4;
-    s->ws.hit_p = (float *)p, p += 3 * cap * 4;
-    s->ws.queue[0] = (float *)p, p += 10 * cap * 4;
-    s->ws.queue[1] = (float *)p, p += 10 * cap * 4;
+    for (HitList &h : s->ws.hits) {
+        h.slot = (int32_t *)p, p += cap * 4;
+        h.tri = (int32_t *)p, p += cap * 4;
+        h.child = (int32_t *)p, p += cap * 4;
+        h.p = (float *)p, p += 3 * cap * 4;
+    }
+    for (float *&q : s->ws.queue) q = (float *)p, p += 10 * cap * 4;
     s->ws.clear = (uint8_t *)p, p += nshadow * cap;
     s->ws.capacity = (int32_t)cap;
     return RTAMD_OK;
@@ -328,6 +334,8 @@ int rtamd_scene_destroy(rtamd_scene *s) {
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
     }
+    for (hipEvent_t e : s->sync) (void)hipEventDestroy(e);
+    if (s->geometry_stream) (void)hipStreamDestroy(s->geometry_stream);
     delete s;
     return RTAMD_OK;
 }
@@ -383,6 +391,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     const bool count = (p->flags & RTAMD_FLAG_COUNT_WORK) != 0;
     const bool timed = (p->flags & RTAMD_FLAG_TIME_KERNELS) != 0;
     size_t open_slot = 0;
+    hipStream_t stream_of_launch = stream; // timing events are recorded on the stream their kernel runs on
     auto begin = [&](int kind) -> int {
         if (!timed) return RTAMD_OK;
         if (s->events_used == s->events.size()) {
@@ -394,12 +403,12 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
         }
         open_slot = s->events_used++;
         s->events[open_slot].kind = kind;
-        HIP_TRY(hipEventRecord(s->events[open_slot].start, stream));
+        HIP_TRY(hipEventRecord(s->events[open_slot].start, stream_of_launch));
         return RTAMD_OK;
     };
     auto end = [&]() -> int {
         if (!timed) return RTAMD_OK;
-        HIP_TRY(hipEventRecord(s->events[open_slot].stop, stream));
+        HIP_TRY(hipEventRecord(s->events[open_slot].stop, stream_of_launch));
         return RTAMD_OK;
     };
     size_t frame_slot = 0;
@@ -408,6 +417,26 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
         frame_slot = open_slot;
     }
 
+    // Two chains per SSAA pass.  Geometry: walk(d) -> compact(d) (which also spawns the rays of depth d+1), for
+    // d = 0, 1, ...; lighting: shadow walk(d) -> shade(d).  Lighting of depth d needs only compact(d), so with
+    // reflections the geometry chain runs ahead on a second stream and the small, latency-bound launches of the
+    // deeper stages overlap the large shadow launch of the stage before.  Buffers rotate (hit lists by d & 1,
+    // queues by d % 3): compact(d + 2) is the first kernel to overwrite what shade(d) reads, and waits for it.
+    const bool two_streams = depths > 1;
+    hipStream_t geo = stream;
+    if (two_streams) {
+        if (!s->geometry_stream) HIP_TRY(hipStreamCreateWithFlags(&s->geometry_stream, hipStreamNonBlocking));
+        geo = s->geometry_stream;
+        while (s->sync.size() < (size_t)(2 * depths + 1)) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            s->sync.push_back(e);
+        }
+    }
+    auto compacted = [&](int d) { return s->sync[(size_t)(1 + 2 * d)]; };
+    auto shaded = [&](int d) { return s->sync[(size_t)(2 + 2 * d)]; };
+    const bool deep_bg = p->background_deep[0] != 0.0f || p->background_deep[1] != 0.0f || p->background_deep[2] != 0.0f;
+
     HIP_TRY(hipMemsetAsync(s->ws_block, 0, 4096, stream));
     int stage = 0;
     for (int xs = 0; xs < S; ++xs)
@@ -415,23 +444,40 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
             fc.sub_x = (float)xs / S; // src/flyscene.cpp:816-817
             fc.sub_y = (float)ys / S;
             fc.accumulate = (xs | ys) != 0;
+            if (two_streams) { // everything enqueued so far (counters cleared, previous pass shaded) precedes this pass
+                HIP_TRY(hipEventRecord(s->sync[0], stream));
+                HIP_TRY(hipStreamWaitEvent(geo, s->sync[0], 0));
+            }
             for (int d = 0; d < depths; ++d, ++stage) {
+                const bool spawn = d + 1 < depths;
+                // ---- geometry chain
+                stream_of_launch = geo;
                 if ((rc = begin(0)) != RTAMD_OK) return rc;
-                launch_walk_closest(d == 0, count, s->ds, fc, s->ws, stage, d & 1, stream);
+                launch_walk_closest(d == 0, count, s->ds, fc, s->ws, stage, d, geo);
                 if ((rc = end()) != RTAMD_OK) return rc;
+                if (two_streams && d >= 2) HIP_TRY(hipStreamWaitEvent(geo, shaded(d - 2), 0));
                 if ((rc = begin(2)) != RTAMD_OK) return rc;
-                launch_compact(d == 0, s->ds, fc, s->ws, stage, d & 1, rgb, face_id, t_hit, stream);
+                launch_compact(d == 0, s->ds, fc, s->ws, stage, d, spawn, deep_bg && d > 0, rgb, face_id, t_hit, geo);
                 if ((rc = end()) != RTAMD_OK) return rc;
+                if (two_streams) {
+                    HIP_TRY(hipEventRecord(compacted(d), geo));
+                    HIP_TRY(hipStreamWaitEvent(stream, compacted(d), 0));
+                }
+                // ---- lighting chain
+                stream_of_launch = stream;
                 if (nshadow > 0) {
                     if ((rc = begin(1)) != RTAMD_OK) return rc;
-                    launch_walk_shadow(count, s->ds, fc, s->ws, stage, stream);
+                    launch_walk_shadow(count, s->ds, fc, s->ws, stage, d, stream);
                     if ((rc = end()) != RTAMD_OK) return rc;
                 }
                 if ((rc = begin(3)) != RTAMD_OK) return rc;
-                launch_shade(d == 0, s->ds, fc, s->ws, stage, d & 1, d + 1 < depths, rgb, stream);
+                launch_shade(d == 0, s->ds, fc, s->ws, stage, d, spawn, rgb, stream);
+                if (deep_bg && d > 0) launch_misses(fc, s->ws, stage, d, rgb, stream);
                 if ((rc = end()) != RTAMD_OK) return rc;
+                if (two_streams) HIP_TRY(hipEventRecord(shaded(d), stream));
             }
         }
+    stream_of_launch = stream;
     if (S > 1) {
         if ((rc = begin(4)) != RTAMD_OK) return rc;
         launch_scale(rgb, pixels * 3, (float)(S * S), stream);

@@ -38,14 +38,23 @@ struct FrameConst {
 
 // Per-stage counters (one stage = one recursion level of one SSAA pass), zeroed once per frame.
 struct StageCounters {
-    int32_t hits;          // entries of the hit list (written by the compaction kernel)
-    int32_t next;          // rays appended to the next queue by the shading kernel
-    int32_t cursor_trace;  // work cursor of the closest-hit kernel
-    int32_t cursor_shadow; // work cursor of the shadow kernel
+    int32_t hits;   // entries of the hit list (written by the compaction kernel)
+    int32_t next;   // rays appended to the next queue (written by the compaction kernel)
+    int32_t misses; // bounce rays that hit nothing, listed only when a deep background colour is set
+    int32_t pad;
 };
 
 struct WorkCounters {
     unsigned long long box_tests, tri_plane, tri_edge, pad;
+};
+
+// Hit list of one stage: positions 0..hits-1, written by the compaction kernel.  Two lists alternate by
+// recursion depth so that the lighting of depth d can run while depth d+1 is traced.
+struct HitList {
+    int32_t *slot;  // ray slot: tile-ordered pixel (primary) or queue index (bounce); misses are listed from the back
+    int32_t *tri;   // TriRecord index, -1 sphere
+    int32_t *child; // index of the reflection ray in the next queue, -1 none
+    float *p;       // 3 planes of `capacity`: hit point
 };
 
 // Work buffers in HBM, sized for `capacity` ray slots (= pixels of the local image, padded to whole tiles).
@@ -54,13 +63,12 @@ struct Workspace {
     // per ray slot, written by the closest-hit kernel
     int32_t *slot_tri; // TriRecord index, -1 sphere, -2 miss
     float *slot_t;     // hit distance
-    // hit list of the current stage (positions 0..hits-1), written by the compaction kernel
-    int32_t *hit_slot; // ray slot: tile-ordered pixel (primary) or queue index (bounce)
-    int32_t *hit_tri;
-    float *hit_p;      // 3 planes of `capacity`: hit point
+    HitList hits[2];   // by depth & 1
     uint8_t *clear;    // [lights*samples][capacity]: 1 = the shadow ray of that sample is unoccluded
-    // ray queues, ping-pong; 10 planes of `capacity` each: o.xyz, d.xyz, throughput.rgb, pixel(bits)
-    float *queue[2];
+    // ray queues, rotating by depth % 3; 10 planes of `capacity` each: o.xyz, d.xyz, throughput.rgb, pixel(bits).
+    // Geometry and pixel are written when the ray is spawned (compaction kernel of the parent depth), the
+    // throughput later by the shading kernel of the parent depth.
+    float *queue[3];
     StageCounters *stage; // kMaxStages
     WorkCounters *work;   // [0] closest-hit kernel, [1] shadow kernel
 };

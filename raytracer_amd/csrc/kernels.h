@@ -9,13 +9,15 @@
 
 namespace rtamd {
 
-void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int cur_queue,
+// `depth` = recursion depth of the stage: selects the ray queue (depth % 3) and the hit list (depth & 1).
+void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth,
                          hipStream_t stream);
-void launch_compact(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int cur_queue, float *rgb,
-                    int32_t *face_id, float *t_hit, hipStream_t stream);
-void launch_walk_shadow(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, hipStream_t stream);
-void launch_shade(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int cur_queue, int spawn, float *rgb,
+void launch_compact(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, bool spawn,
+                    bool list_misses, float *rgb, int32_t *face_id, float *t_hit, hipStream_t stream);
+void launch_walk_shadow(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, hipStream_t stream);
+void launch_shade(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, bool spawn, float *rgb,
                   hipStream_t stream);
+void launch_misses(const FrameConst &fc, const Workspace &ws, int stage, int depth, float *rgb, hipStream_t stream);
 void launch_scale(float *rgb, size_t n, float divisor, hipStream_t stream);
 void launch_assemble(const void *src, void *dst, int width, int height, int channels, int row_tile, int num_parts, hipStream_t stream);
 

@@ -68,6 +68,7 @@ __device__ __forceinline__ float smax(float a, float b) { return a < b ? b : a; 
 __device__ __forceinline__ float smin(float a, float b) { return b < a ? b : a; }
 
 __device__ __forceinline__ float *plane(float *base, int capacity, int k) { return base + (size_t)k * (size_t)capacity; }
+__device__ __forceinline__ const float *plane(const float *base, int capacity, int k) { return base + (size_t)k * (size_t)capacity; }
 
 // ---------------------------------------------------------------------------------------------
 // Camera ray of one pixel sample: Camera::screenToWorld (camera.hpp:158-176, double intermediates
@@ -199,7 +200,7 @@ __device__ __forceinline__ int stack_read(const int *stack, const int *deep, int
 }
 
 template <int MODE, bool COUNT>
-__global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int cur_queue, int total_static) {
+__global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth, int total_static) {
     __shared__ int s_stack[(kLdsStack + kLeafQueue) * 64];
     int deep[kStackEntries - kLdsStack > 0 ? kStackEntries - kLdsStack : 1];
     constexpr bool ANY = MODE == kShadow;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
             valid = valid && item < rays;
             out_index = item;
             if (valid) {
-                float *qd = ws.queue[cur_queue];
+                float *qd = ws.queue[depth % 3];
                 o = mk(plane(qd, ws.capacity, 0)[item], plane(qd, ws.capacity, 1)[item], plane(qd, ws.capacity, 2)[item]);
                 d = mk(plane(qd, ws.capacity, 3)[item], plane(qd, ws.capacity, 4)[item], plane(qd, ws.capacity, 5)[item]);
             }
@@ -254,7 +255,8 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
             valid = valid && hit < nhits;
             out_index = sample * ws.capacity + hit;
             if (valid) {
-                o = mk(plane(ws.hit_p, ws.capacity, 0)[hit], plane(ws.hit_p, ws.capacity, 1)[hit], plane(ws.hit_p, ws.capacity, 2)[hit]);
+                const float *hp = ws.hits[depth & 1].p;
+                o = mk(hp[hit], hp[(size_t)ws.capacity + hit], hp[2 * (size_t)ws.capacity + hit]);
                 d = mk(sc.samples[3 * sample], sc.samples[3 * sample + 1], sc.samples[3 * sample + 2]);
             }
         }
@@ -263,19 +265,24 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
             continue;
         }
 
-        // Slab test operands: t = fma(bound, inv, -origin * inv).  The inverse is kept finite (a zero direction
-        // component becomes +-1e25) so that no infinity or NaN enters the min/max chains.  origin*inv is rounded
-        // once, which puts an ABSOLUTE error of about one ulp of |origin*inv| on every slab distance of that
-        // axis; `slack` bounds it (two ulps of the largest product; clamped axes are left out: their distances
-        // are exact zeros or astronomically large with a reliable sign) and widens the exit distance.
+        // Slab test operands: t = fma(bound, inv, -origin * inv), near bound and far bound picked by the sign of
+        // the direction.  The inverse is kept finite (a zero direction component becomes +-1e25) so that no
+        // infinity or NaN enters the min/max chains.  origin*inv is rounded once, which puts an ABSOLUTE error of
+        // up to half an ulp of |origin*inv| on every slab distance of that axis; each axis widens its own
+        // interval by one ulp (folded into the addends), so a nearly axis-parallel ray, whose products are
+        // astronomically large on one axis, still culls normally on the other two.  Clamped axes are not widened:
+        // their distances are exact zeros or astronomically large with a reliable sign.
         constexpr float kInvMax = 1e25f;
         float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
         const bool cx = !(fabsf(ix) <= kInvMax), cy = !(fabsf(iy) <= kInvMax), cz = !(fabsf(iz) <= kInvMax);
         if (cx) ix = copysignf(kInvMax, d.x);
         if (cy) iy = copysignf(kInvMax, d.y);
         if (cz) iz = copysignf(kInvMax, d.z);
+        const bool negx = ix < 0.0f, negy = iy < 0.0f, negz = iz < 0.0f;
         const float bx = -o.x * ix, by = -o.y * iy, bz = -o.z * iz;
-        const float slack = 2.4e-7f * fmaxf(fmaxf(cx ? 0.0f : fabsf(bx), cy ? 0.0f : fabsf(by)), cz ? 0.0f : fabsf(bz));
+        const float ex = cx ? 0.0f : 1.2e-7f * fabsf(bx), ey = cy ? 0.0f : 1.2e-7f * fabsf(by), ez = cz ? 0.0f : 1.2e-7f * fabsf(bz);
+        const float bnx = bx - ex, bny = by - ey, bnz = bz - ez; // addends of entry distances
+        const float bfx = bx + ex, bfy = by + ey, bfz = bz + ez; // addends of exit distances
 
         float tbest = FLT_MAX;
         int best_tri = -2, best_rank = -1;
@@ -310,18 +317,20 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
                 const float4 nz = sc.nodes[node * 4 + 2];
                 const float4 nc = sc.nodes[node * 4 + 3];
                 if (COUNT) w_box += 2;
-                const float a0 = __builtin_fmaf(nx.x, ix, bx), a1 = __builtin_fmaf(nx.y, ix, bx);
-                const float b0 = __builtin_fmaf(ny.x, iy, by), b1 = __builtin_fmaf(ny.y, iy, by);
-                const float c0 = __builtin_fmaf(nz.x, iz, bz), c1 = __builtin_fmaf(nz.y, iz, bz);
-                const float n0 = fmaxf(fmaxf(fminf(a0, a1), fminf(b0, b1)), fmaxf(fminf(c0, c1), 0.0f));
-                const float f0 = fminf(fminf(fmaxf(a0, a1), fmaxf(b0, b1)), fminf(fmaxf(c0, c1), tlimit));
-                const float d0 = __builtin_fmaf(nx.z, ix, bx), d1 = __builtin_fmaf(nx.w, ix, bx);
-                const float e0 = __builtin_fmaf(ny.z, iy, by), e1 = __builtin_fmaf(ny.w, iy, by);
-                const float g0 = __builtin_fmaf(nz.z, iz, bz), g1 = __builtin_fmaf(nz.w, iz, bz);
-                const float n1 = fmaxf(fmaxf(fminf(d0, d1), fminf(e0, e1)), fmaxf(fminf(g0, g1), 0.0f));
-                const float f1 = fminf(fminf(fmaxf(d0, d1), fmaxf(e0, e1)), fminf(fmaxf(g0, g1), tlimit));
-                const bool h0 = n0 <= __builtin_fmaf(f0, 1.0000005f, slack);
-                const bool h1 = n1 <= __builtin_fmaf(f1, 1.0000005f, slack);
+                // per axis the node holds (child0.min, child0.max, child1.min, child1.max)
+                const float n0x = __builtin_fmaf(negx ? nx.y : nx.x, ix, bnx), f0x = __builtin_fmaf(negx ? nx.x : nx.y, ix, bfx);
+                const float n0y = __builtin_fmaf(negy ? ny.y : ny.x, iy, bny), f0y = __builtin_fmaf(negy ? ny.x : ny.y, iy, bfy);
+                const float n0z = __builtin_fmaf(negz ? nz.y : nz.x, iz, bnz), f0z = __builtin_fmaf(negz ? nz.x : nz.y, iz, bfz);
+                const float n1x = __builtin_fmaf(negx ? nx.w : nx.z, ix, bnx), f1x = __builtin_fmaf(negx ? nx.z : nx.w, ix, bfx);
+                const float n1y = __builtin_fmaf(negy ? ny.w : ny.z, iy, bny), f1y = __builtin_fmaf(negy ? ny.z : ny.w, iy, bfy);
+                const float n1z = __builtin_fmaf(negz ? nz.w : nz.z, iz, bnz), f1z = __builtin_fmaf(negz ? nz.z : nz.w, iz, bfz);
+                const float n0 = fmaxf(fmaxf(n0x, n0y), fmaxf(n0z, 0.0f));
+                const float f0 = fminf(fminf(f0x, f0y), fminf(f0z, tlimit));
+                const float n1 = fmaxf(fmaxf(n1x, n1y), fmaxf(n1z, 0.0f));
+                const float f1 = fminf(fminf(f1x, f1y), fminf(f1z, tlimit));
+                // the factor covers the relative rounding of the distances themselves
+                const bool h0 = n0 <= f0 * 1.0000005f;
+                const bool h1 = n1 <= f1 * 1.0000005f;
                 const int c0i = __float_as_int(nc.x), c1i = __float_as_int(nc.y);
                 if (h0 && h1) {
                     const bool first0 = n0 <= n1;
@@ -399,18 +408,21 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
 }
 
 // ---------------------------------------------------------------------------------------------
-// Compaction: ray slots that hit something -> dense hit list, in slot order inside a workgroup and
-// one atomic per workgroup.  Also writes the hit point, the primary planes (face id, distance) and
-// the colour of rays that hit nothing (src/flyscene.cpp:650-666).
+// Compaction: ray slots that hit something -> dense hit list (slot order inside a workgroup, one atomic
+// per workgroup and list).  Also writes the hit point, the primary planes (face id, distance), the colour
+// of primary rays that hit nothing (src/flyscene.cpp:650-658), and -- the reflection set-up of traceRay,
+// src/flyscene.cpp:617-646 -- geometry and pixel of the reflection ray into the next queue.  The ray's
+// throughput needs the light intensity and is filled in later by the shading kernel, through `child`.
 // ---------------------------------------------------------------------------------------------
 template <bool PRIMARY>
-__global__ __launch_bounds__(256) void compact_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int cur_queue, float *rgb,
-                                                      int32_t *face_id, float *t_hit, int total_static) {
-    __shared__ int s_wave_count[4];
-    __shared__ int s_base;
+__global__ __launch_bounds__(256) void compact_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth, int spawn, int list_misses,
+                                                      float *rgb, int32_t *face_id, float *t_hit, int total_static) {
+    __shared__ int s_count[3][4];
+    __shared__ int s_base[3];
     const int total = PRIMARY ? total_static : ws.stage[stage - 1].next;
     const int first = (int)blockIdx.x * 256;
     if (first >= total) return;
+    const HitList hl = ws.hits[depth & 1];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = first + tid;
     bool valid = slot < total;
@@ -418,9 +430,10 @@ __global__ __launch_bounds__(256) void compact_kernel(DeviceScene sc, FrameConst
     if (PRIMARY && valid) valid = slot_pixel(fc, slot, x, row);
     const int tri = valid ? ws.slot_tri[slot] : -2;
     const bool hit = tri != -2;
+    const bool miss = list_misses && valid && !hit;
     const float t = hit ? ws.slot_t[slot] : 0.0f;
 
-    V3 o, d;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
     int pix = 0;
     if (PRIMARY) {
         pix = row * fc.width + x;
@@ -438,163 +451,180 @@ __global__ __launch_bounds__(256) void compact_kernel(DeviceScene sc, FrameConst
         }
         o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
         if (hit) d = primary_direction(fc, x, row);
-    } else if (valid) {
-        float *q = ws.queue[cur_queue];
-        if (hit) {
-            o = mk(plane(q, ws.capacity, 0)[slot], plane(q, ws.capacity, 1)[slot], plane(q, ws.capacity, 2)[slot]);
-            d = mk(plane(q, ws.capacity, 3)[slot], plane(q, ws.capacity, 4)[slot], plane(q, ws.capacity, 5)[slot]);
-        } else if (fc.bg_deep[0] != 0.0f || fc.bg_deep[1] != 0.0f || fc.bg_deep[2] != 0.0f) {
-            // a deeper miss adds throughput * background_deep (zero in the reference, :661-665)
-            float *p = rgb + 3 * (size_t)__float_as_int(plane(q, ws.capacity, 9)[slot]);
-            p[0] += plane(q, ws.capacity, 6)[slot] * fc.bg_deep[0];
-            p[1] += plane(q, ws.capacity, 7)[slot] * fc.bg_deep[1];
-            p[2] += plane(q, ws.capacity, 8)[slot] * fc.bg_deep[2];
+    } else if (hit) {
+        const float *q = ws.queue[depth % 3];
+        o = mk(plane(q, ws.capacity, 0)[slot], plane(q, ws.capacity, 1)[slot], plane(q, ws.capacity, 2)[slot]);
+        d = mk(plane(q, ws.capacity, 3)[slot], plane(q, ws.capacity, 4)[slot], plane(q, ws.capacity, 5)[slot]);
+        pix = __float_as_int(plane(q, ws.capacity, 9)[slot]);
+    }
+    const V3 hp = o + t * d; // hitPoint, :709,771
+
+    // does this hit reflect?  :617-632 (a sphere ends the path, :618-621)
+    bool go = false;
+    V3 fn = mk(0, 0, 1);
+    if (spawn && hit && tri >= 0) {
+        const int face = __float_as_int(sc.tris[tri * 4 + 1].w);
+        const float4 s4 = sc.shade[face * 6 + 4], s5 = sc.shade[face * 6 + 5];
+        const int mat = __float_as_int(s5.y);
+        if (mat >= 0 && mat < sc.num_materials) {
+            const float *mp = sc.materials + 10 * mat;
+            go = mp[6] > fc.refl_thresh || mp[7] > fc.refl_thresh || mp[8] > fc.refl_thresh; // :631-632
+            fn = mk(s4.z, s4.w, s5.x);
         }
     }
 
-    const unsigned long long m = __ballot(hit);
-    if (lane == 0) s_wave_count[wave] = __popcll(m);
-    __syncthreads();
-    if (tid == 0) {
-        const int n = s_wave_count[0] + s_wave_count[1] + s_wave_count[2] + s_wave_count[3];
-        s_base = n ? atomicAdd(&ws.stage[stage].hits, n) : 0;
+    const unsigned long long m_hit = __ballot(hit), m_go = __ballot(go), m_miss = __ballot(miss);
+    if (lane == 0) {
+        s_count[0][wave] = __popcll(m_hit);
+        s_count[1][wave] = __popcll(m_go);
+        s_count[2][wave] = __popcll(m_miss);
     }
     __syncthreads();
+    if (tid < 3) {
+        const int n = s_count[tid][0] + s_count[tid][1] + s_count[tid][2] + s_count[tid][3];
+        int *counter = tid == 0 ? &ws.stage[stage].hits : tid == 1 ? &ws.stage[stage].next : &ws.stage[stage].misses;
+        s_base[tid] = n ? atomicAdd(counter, n) : 0;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int child = -1;
+    if (go) {
+        int pos = s_base[1] + __popcll(m_go & below);
+        for (int w = 0; w < wave; ++w) pos += s_count[1][w];
+        child = pos;
+        const V3 refl = normalized(d - (2 * dot(d, fn)) * fn); // :785 then :635
+        const V3 no = hp + fc.bounce_off * refl;               // :636
+        float *q = ws.queue[(depth + 1) % 3];
+        plane(q, ws.capacity, 0)[pos] = no.x, plane(q, ws.capacity, 1)[pos] = no.y, plane(q, ws.capacity, 2)[pos] = no.z;
+        plane(q, ws.capacity, 3)[pos] = refl.x, plane(q, ws.capacity, 4)[pos] = refl.y, plane(q, ws.capacity, 5)[pos] = refl.z;
+        plane(q, ws.capacity, 9)[pos] = __int_as_float(pix);
+    }
     if (hit) {
-        int pos = s_base + __popcll(m & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave; ++w) pos += s_wave_count[w];
-        const V3 hp = o + t * d; // hitPoint, :709,771
-        ws.hit_slot[pos] = slot;
-        ws.hit_tri[pos] = tri;
-        plane(ws.hit_p, ws.capacity, 0)[pos] = hp.x;
-        plane(ws.hit_p, ws.capacity, 1)[pos] = hp.y;
-        plane(ws.hit_p, ws.capacity, 2)[pos] = hp.z;
+        int pos = s_base[0] + __popcll(m_hit & below);
+        for (int w = 0; w < wave; ++w) pos += s_count[0][w];
+        hl.slot[pos] = slot;
+        hl.tri[pos] = tri;
+        if (spawn) hl.child[pos] = child;
+        plane(hl.p, ws.capacity, 0)[pos] = hp.x;
+        plane(hl.p, ws.capacity, 1)[pos] = hp.y;
+        plane(hl.p, ws.capacity, 2)[pos] = hp.z;
     }
+    if (miss) {
+        int pos = s_base[2] + __popcll(m_miss & below);
+        for (int w = 0; w < wave; ++w) pos += s_count[2][w];
+        hl.slot[ws.capacity - 1 - pos] = slot; // hits + misses <= rays <= capacity: the two ends never meet
+    }
+}
+
+// A bounce ray that hits nothing adds throughput * background_deep (zero in the reference,
+// src/flyscene.cpp:661-665, so this kernel only runs when a caller sets that colour).
+__global__ __launch_bounds__(256) void miss_kernel(FrameConst fc, Workspace ws, int stage, int depth, float *rgb) {
+    const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (idx >= ws.stage[stage].misses) return;
+    const int slot = ws.hits[depth & 1].slot[ws.capacity - 1 - idx];
+    const float *q = ws.queue[depth % 3];
+    float *p = rgb + 3 * (size_t)__float_as_int(plane(q, ws.capacity, 9)[slot]);
+    p[0] += plane(q, ws.capacity, 6)[slot] * fc.bg_deep[0];
+    p[1] += plane(q, ws.capacity, 7)[slot] * fc.bg_deep[1];
+    p[2] += plane(q, ws.capacity, 8)[slot] * fc.bg_deep[2];
 }
 
 // ---------------------------------------------------------------------------------------------
 // Shading: one lane per entry of the hit list.
 // ---------------------------------------------------------------------------------------------
 template <bool PRIMARY>
-__global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int cur_queue, int spawn, float *rgb) {
-    __shared__ int s_wave_count[4];
-    __shared__ int s_base;
+__global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth, int spawn, float *rgb) {
     const int nhits = ws.stage[stage].hits;
-    const int first = (int)blockIdx.x * 256;
-    if (first >= nhits) return;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int idx = first + tid;
-    const bool valid = idx < nhits;
+    const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (idx >= nhits) return;
+    const HitList hl = ws.hits[depth & 1];
 
-    bool go = false;
-    V3 P = mk(0, 0, 0), rd = mk(0, 0, 1), T = mk(0, 0, 0), ks = mk(0, 0, 0), fn = mk(0, 0, 1), LI = mk(0, 0, 0);
-    int pix = 0;
-    if (valid) {
-        P = mk(plane(ws.hit_p, ws.capacity, 0)[idx], plane(ws.hit_p, ws.capacity, 1)[idx], plane(ws.hit_p, ws.capacity, 2)[idx]);
-        // getLightIntensity, src/flyscene.cpp:870-896: share of unoccluded samples per light, summed, capped at 1
-        float li = 0.0f;
-        for (int l = 0; l < sc.num_lights; ++l) {
-            float reaching = 0.0f;
-            for (int k = 0; k < sc.spl; ++k) reaching += (float)ws.clear[(size_t)(l * sc.spl + k) * ws.capacity + idx];
-            li += reaching / (float)sc.spl;
-        }
-        li = smin(li, 1.0f);
-        LI = mk(li, li, li);
+    const V3 P = mk(plane(hl.p, ws.capacity, 0)[idx], plane(hl.p, ws.capacity, 1)[idx], plane(hl.p, ws.capacity, 2)[idx]);
+    // getLightIntensity, src/flyscene.cpp:870-896: share of unoccluded samples per light, summed, capped at 1
+    float li = 0.0f;
+    for (int l = 0; l < sc.num_lights; ++l) {
+        float reaching = 0.0f;
+        for (int k = 0; k < sc.spl; ++k) reaching += (float)ws.clear[(size_t)(l * sc.spl + k) * ws.capacity + idx];
+        li += reaching / (float)sc.spl;
+    }
+    li = smin(li, 1.0f);
+    const V3 LI = mk(li, li, li);
 
-        // the ray that produced this hit
-        const int slot = ws.hit_slot[idx];
-        const int tri = ws.hit_tri[idx];
-        V3 ro;
-        if (PRIMARY) {
-            int x, row;
-            slot_pixel(fc, slot, x, row);
-            pix = row * fc.width + x;
-            ro = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
-            rd = primary_direction(fc, x, row);
-            T = mk(1.0f, 1.0f, 1.0f);
+    // the ray that produced this hit
+    const int slot = hl.slot[idx];
+    const int tri = hl.tri[idx];
+    V3 ro, T, ks = mk(0, 0, 0);
+    int pix;
+    if (PRIMARY) {
+        int x, row;
+        slot_pixel(fc, slot, x, row);
+        pix = row * fc.width + x;
+        ro = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
+        T = mk(1.0f, 1.0f, 1.0f);
+    } else {
+        const float *q = ws.queue[depth % 3];
+        ro = mk(plane(q, ws.capacity, 0)[slot], plane(q, ws.capacity, 1)[slot], plane(q, ws.capacity, 2)[slot]);
+        T = mk(plane(q, ws.capacity, 6)[slot], plane(q, ws.capacity, 7)[slot], plane(q, ws.capacity, 8)[slot]);
+        pix = __float_as_int(plane(q, ws.capacity, 9)[slot]);
+    }
+
+    // shadeOffFace, src/flyscene.cpp:461-579
+    V3 local;
+    if (tri < 0) {
+        local = mk(0.7f, 0.9f, 0.0f); // sphere, :463-465
+    } else {
+        const int face = __float_as_int(sc.tris[tri * 4 + 1].w);
+        const float4 s0 = sc.shade[face * 6 + 0], s1 = sc.shade[face * 6 + 1], s2 = sc.shade[face * 6 + 2];
+        const float4 s3 = sc.shade[face * 6 + 3], s4 = sc.shade[face * 6 + 4], s5 = sc.shade[face * 6 + 5];
+        const V3 v0 = mk(s0.x, s0.y, s0.z), v1 = mk(s0.w, s1.x, s1.y), v2 = mk(s1.z, s1.w, s2.x);
+        const V3 n0 = mk(s2.y, s2.z, s2.w), n1 = mk(s3.x, s3.y, s3.z), n2 = mk(s3.w, s4.x, s4.y);
+        const int mat = __float_as_int(s5.y);
+        if (mat < 0 || mat >= sc.num_materials) {
+            local = mk(0.5f, 0.5f, 0.5f); // :469-472
         } else {
-            float *q = ws.queue[cur_queue];
-            ro = mk(plane(q, ws.capacity, 0)[slot], plane(q, ws.capacity, 1)[slot], plane(q, ws.capacity, 2)[slot]);
-            rd = mk(plane(q, ws.capacity, 3)[slot], plane(q, ws.capacity, 4)[slot], plane(q, ws.capacity, 5)[slot]);
-            T = mk(plane(q, ws.capacity, 6)[slot], plane(q, ws.capacity, 7)[slot], plane(q, ws.capacity, 8)[slot]);
-            pix = __float_as_int(plane(q, ws.capacity, 9)[slot]);
-        }
-
-        // shadeOffFace, src/flyscene.cpp:461-579
-        V3 local;
-        bool reflect = false;
-        if (tri < 0) {
-            local = mk(0.7f, 0.9f, 0.0f); // sphere, :463-465
-        } else {
-            const int face = __float_as_int(sc.tris[tri * 4 + 1].w);
-            const float4 s0 = sc.shade[face * 6 + 0], s1 = sc.shade[face * 6 + 1], s2 = sc.shade[face * 6 + 2];
-            const float4 s3 = sc.shade[face * 6 + 3], s4 = sc.shade[face * 6 + 4], s5 = sc.shade[face * 6 + 5];
-            const V3 v0 = mk(s0.x, s0.y, s0.z), v1 = mk(s0.w, s1.x, s1.y), v2 = mk(s1.z, s1.w, s2.x);
-            const V3 n0 = mk(s2.y, s2.z, s2.w), n1 = mk(s3.x, s3.y, s3.z), n2 = mk(s3.w, s4.x, s4.y);
-            fn = mk(s4.z, s4.w, s5.x);
-            const int mat = __float_as_int(s5.y);
-            if (mat < 0 || mat >= sc.num_materials) {
-                local = mk(0.5f, 0.5f, 0.5f); // :469-472
-            } else {
-                const float *mp = sc.materials + 10 * mat;
-                const V3 ka = mk(mp[0], mp[1], mp[2]), kd = mk(mp[3], mp[4], mp[5]);
-                ks = mk(mp[6], mp[7], mp[8]);
-                const float shininess = mp[9];
-                // area-weighted normal, :494-500
-                const float a12 = norm(cross(v1 - P, v2 - P)) * 0.5f;
-                const float a02 = norm(cross(v0 - P, v2 - P)) * 0.5f;
-                const float a01 = norm(cross(v0 - P, v1 - P)) * 0.5f;
-                const V3 N = normalized((a12 * n0 + a02 * n1) + a01 * n2);
-                local = mk(0.0f, 0.0f, 0.0f);
-                for (int l = 0; l < sc.num_lights; ++l) {
-                    const V3 lp = mk(sc.light_pos[3 * l], sc.light_pos[3 * l + 1], sc.light_pos[3 * l + 2]);
-                    const V3 L = normalized(lp - P);                          // :507
-                    const V3 ambient = cmul(LI, ka);                          // :510
-                    const float cos1 = fmaxf(0.0f, dot(L, N));                // :513
-                    const V3 diffuse = cos1 * cmul(LI, kd);                   // :514
-                    const V3 E = normalized(ro - P);                          // :545
-                    const V3 R = normalized(-L + (2.f * dot(L, N)) * N);      // :546
-                    const float cos2 = fmaxf(0.0f, dot(R, E));                // :548
-                    const V3 specular = powf(cos2, shininess) * cmul(LI, ks); // :549
-                    const V3 sum = (diffuse + specular) + ambient;            // :554
-                    local = local + mk(smin(smax(sum.x, 0.0f), 1.0f), smin(smax(sum.y, 0.0f), 1.0f), smin(smax(sum.z, 0.0f), 1.0f));
-                }
-                reflect = ks.x > fc.refl_thresh || ks.y > fc.refl_thresh || ks.z > fc.refl_thresh; // :631-632
+            const float *mp = sc.materials + 10 * mat;
+            const V3 ka = mk(mp[0], mp[1], mp[2]), kd = mk(mp[3], mp[4], mp[5]);
+            ks = mk(mp[6], mp[7], mp[8]);
+            const float shininess = mp[9];
+            // area-weighted normal, :494-500
+            const float a12 = norm(cross(v1 - P, v2 - P)) * 0.5f;
+            const float a02 = norm(cross(v0 - P, v2 - P)) * 0.5f;
+            const float a01 = norm(cross(v0 - P, v1 - P)) * 0.5f;
+            const V3 N = normalized((a12 * n0 + a02 * n1) + a01 * n2);
+            local = mk(0.0f, 0.0f, 0.0f);
+            for (int l = 0; l < sc.num_lights; ++l) {
+                const V3 lp = mk(sc.light_pos[3 * l], sc.light_pos[3 * l + 1], sc.light_pos[3 * l + 2]);
+                const V3 L = normalized(lp - P);                          // :507
+                const V3 ambient = cmul(LI, ka);                          // :510
+                const float cos1 = fmaxf(0.0f, dot(L, N));                // :513
+                const V3 diffuse = cos1 * cmul(LI, kd);                   // :514
+                const V3 E = normalized(ro - P);                          // :545
+                const V3 R = normalized(-L + (2.f * dot(L, N)) * N);      // :546
+                const float cos2 = fmaxf(0.0f, dot(R, E));                // :548
+                const V3 specular = powf(cos2, shininess) * cmul(LI, ks); // :549
+                const V3 sum = (diffuse + specular) + ambient;            // :554
+                local = local + mk(smin(smax(sum.x, 0.0f), 1.0f), smin(smax(sum.y, 0.0f), 1.0f), smin(smax(sum.z, 0.0f), 1.0f));
             }
         }
+    }
 
-        // pixel += throughput * local.  Each pixel owns at most one live path, so no atomics are needed.
-        float *p = rgb + 3 * (size_t)pix;
-        if (PRIMARY && !fc.accumulate) {
-            p[0] = local.x, p[1] = local.y, p[2] = local.z;
-        } else {
-            const V3 add = cmul(T, local);
-            p[0] += add.x, p[1] += add.y, p[2] += add.z;
+    // pixel += throughput * local.  Each pixel owns at most one live path, so no atomics are needed.
+    float *p = rgb + 3 * (size_t)pix;
+    if (PRIMARY && !fc.accumulate) {
+        p[0] = local.x, p[1] = local.y, p[2] = local.z;
+    } else {
+        const V3 add = cmul(T, local);
+        p[0] += add.x, p[1] += add.y, p[2] += add.z;
+    }
+
+    // throughput of the reflection ray spawned from this hit: local + C_next * ks * LI, :637,645
+    if (spawn) {
+        const int child = hl.child[idx];
+        if (child >= 0) {
+            const V3 nT = cmul(cmul(T, ks), LI);
+            float *q = ws.queue[(depth + 1) % 3];
+            plane(q, ws.capacity, 6)[child] = nT.x, plane(q, ws.capacity, 7)[child] = nT.y, plane(q, ws.capacity, 8)[child] = nT.z;
         }
-        go = spawn && reflect;
-    }
-
-    // reflection set-up of traceRay, src/flyscene.cpp:617-646: append to the next queue, one atomic per workgroup
-    if (!spawn) return;
-    const unsigned long long m = __ballot(go);
-    if (lane == 0) s_wave_count[wave] = __popcll(m);
-    __syncthreads();
-    if (tid == 0) {
-        const int n = s_wave_count[0] + s_wave_count[1] + s_wave_count[2] + s_wave_count[3];
-        s_base = n ? atomicAdd(&ws.stage[stage].next, n) : 0;
-    }
-    __syncthreads();
-    if (go) {
-        int pos = s_base + __popcll(m & ((1ull << lane) - 1ull));
-        for (int w = 0; w < wave; ++w) pos += s_wave_count[w];
-        const V3 refl = normalized(rd - (2 * dot(rd, fn)) * fn); // :785 then :635
-        const V3 no = P + fc.bounce_off * refl;                  // :636
-        const V3 nT = cmul(cmul(T, ks), LI);                     // :637
-        float *q = ws.queue[cur_queue ^ 1];
-        plane(q, ws.capacity, 0)[pos] = no.x, plane(q, ws.capacity, 1)[pos] = no.y, plane(q, ws.capacity, 2)[pos] = no.z;
-        plane(q, ws.capacity, 3)[pos] = refl.x, plane(q, ws.capacity, 4)[pos] = refl.y, plane(q, ws.capacity, 5)[pos] = refl.z;
-        plane(q, ws.capacity, 6)[pos] = nT.x, plane(q, ws.capacity, 7)[pos] = nT.y, plane(q, ws.capacity, 8)[pos] = nT.z;
-        plane(q, ws.capacity, 9)[pos] = __int_as_float(pix);
     }
 }
 
@@ -646,50 +676,54 @@ int walk_grid(long long groups) {
 }
 } // namespace
 
-void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int cur_queue,
+void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth,
                          hipStream_t stream) {
     const int total_static = fc.tiles_x * fc.tiles_y * 64;
     // bounce queues are at most as long as the slot count: that is the worst case the grid covers
     const int blocks = walk_grid(primary ? fc.tiles_x * fc.tiles_y : ws.capacity / 64);
     if (primary) {
         if (count)
-            walk_kernel<kPrimary, true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, cur_queue, total_static);
+            walk_kernel<kPrimary, true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, total_static);
         else
-            walk_kernel<kPrimary, false><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, cur_queue, total_static);
+            walk_kernel<kPrimary, false><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, total_static);
     } else {
         if (count)
-            walk_kernel<kQueue, true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, cur_queue, 0);
+            walk_kernel<kQueue, true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, 0);
         else
-            walk_kernel<kQueue, false><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, cur_queue, 0);
+            walk_kernel<kQueue, false><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, 0);
     }
 }
 
-void launch_compact(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int cur_queue, float *rgb,
-                    int32_t *face_id, float *t_hit, hipStream_t stream) {
+void launch_compact(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, bool spawn,
+                    bool list_misses, float *rgb, int32_t *face_id, float *t_hit, hipStream_t stream) {
     const int total_static = fc.tiles_x * fc.tiles_y * 64;
     if (primary)
-        compact_kernel<true><<<(total_static + 255) / 256, 256, 0, stream>>>(sc, fc, ws, stage, cur_queue, rgb, face_id, t_hit, total_static);
+        compact_kernel<true><<<(total_static + 255) / 256, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, 0, rgb, face_id, t_hit, total_static);
     else
-        compact_kernel<false><<<(ws.capacity + 255) / 256, 256, 0, stream>>>(sc, fc, ws, stage, cur_queue, rgb, face_id, t_hit, 0);
+        compact_kernel<false><<<(ws.capacity + 255) / 256, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, list_misses, rgb, face_id, t_hit, 0);
 }
 
-void launch_walk_shadow(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, hipStream_t stream) {
+void launch_walk_shadow(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, hipStream_t stream) {
     const int nshadow = sc.num_lights * sc.spl;
     if (nshadow <= 0) return;
     const int blocks = walk_grid((long long)(fc.tiles_x * fc.tiles_y) * nshadow);
     if (count)
-        walk_kernel<kShadow, true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, 0, 0);
+        walk_kernel<kShadow, true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, 0);
     else
-        walk_kernel<kShadow, false><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, 0, 0);
+        walk_kernel<kShadow, false><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, 0);
 }
 
-void launch_shade(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int cur_queue, int spawn, float *rgb,
+void launch_shade(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, bool spawn, float *rgb,
                   hipStream_t stream) {
     const int sblocks = (ws.capacity + 255) / 256;
     if (primary)
-        shade_kernel<true><<<sblocks, 256, 0, stream>>>(sc, fc, ws, stage, cur_queue, spawn, rgb);
+        shade_kernel<true><<<sblocks, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, rgb);
     else
-        shade_kernel<false><<<sblocks, 256, 0, stream>>>(sc, fc, ws, stage, cur_queue, spawn, rgb);
+        shade_kernel<false><<<sblocks, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, rgb);
+}
+
+void launch_misses(const FrameConst &fc, const Workspace &ws, int stage, int depth, float *rgb, hipStream_t stream) {
+    miss_kernel<<<(ws.capacity + 255) / 256, 256, 0, stream>>>(fc, ws, stage, depth, rgb);
 }
 
 void launch_scale(float *rgb, size_t n, float divisor, hipStream_t stream) {
