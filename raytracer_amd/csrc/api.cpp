@@ -81,9 +81,8 @@ struct rtamd_scene {
     // HIP-event pairs of every launch (kind 0..4) and frame (kind 5) since the last stats call
     std::vector<TimedLaunch> events;
     size_t events_used = 0;
-    // Second stream of a frame with reflections: the closest-hit chain (walk, compact of every depth) runs
-    // here while the caller's stream runs the lighting chain (shadow walk, shade); `sync` orders the two.
-    hipStream_t geometry_stream = nullptr;
+    // Extra streams of a frame with reflections (see rtamd_render_device); `sync` holds the events that order them.
+    hipStream_t geometry_stream = nullptr, deep_shadow_stream = nullptr;
     std::vector<hipEvent_t> sync;
 };
 
@@ -109,7 +108,7 @@ int ensure_workspace(rtamd_scene *s, size_t slots) {
     const size_t nshadow = (size_t)s->ds.num_lights * (size_t)s->ds.spl;
     const size_t planes = 2 /*slot tri, t*/ + 2 * 6 /*two hit lists: slot, tri, child, point*/ + 30 /*three queues*/;
     const size_t head = 4096; // stage counters + work counters
-    const size_t total = head + planes * cap * 4 + nshadow * cap;
+    const size_t total = head + planes * cap * 4 + 2 * nshadow * cap;
     HIP_TRY(hipMalloc(&s->ws_block, total));
     char *base = (char *)s->ws_block;
     s->ws.stage = (StageCounters *)base;
@@ -125,7 +124,7 @@ int ensure_workspace(rtamd_scene *s, size_t slots) {
         h.p = (float *)p, p += 3 * cap * 4;
     }
     for (float *&q : s->ws.queue) q = (float *)p, p += 10 * cap * 4;
-    s->ws.clear = (uint8_t *)p, p += nshadow * cap;
+    for (uint8_t *&c : s->ws.clear) c = (uint8_t *)p, p += nshadow * cap;
     s->ws.capacity = (int32_t)cap;
     return RTAMD_OK;
 }
@@ -336,6 +335,7 @@ int rtamd_scene_destroy(rtamd_scene *s) {
     }
     for (hipEvent_t e : s->sync) (void)hipEventDestroy(e);
     if (s->geometry_stream) (void)hipStreamDestroy(s->geometry_stream);
+    if (s->deep_shadow_stream) (void)hipStreamDestroy(s->deep_shadow_stream);
     delete s;
     return RTAMD_OK;
 }
@@ -417,24 +417,29 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
         frame_slot = open_slot;
     }
 
-    // Two chains per SSAA pass.  Geometry: walk(d) -> compact(d) (which also spawns the rays of depth d+1), for
-    // d = 0, 1, ...; lighting: shadow walk(d) -> shade(d).  Lighting of depth d needs only compact(d), so with
-    // reflections the geometry chain runs ahead on a second stream and the small, latency-bound launches of the
-    // deeper stages overlap the large shadow launch of the stage before.  Buffers rotate (hit lists by d & 1,
-    // queues by d % 3): compact(d + 2) is the first kernel to overwrite what shade(d) reads, and waits for it.
+    // Per SSAA pass the work of depth d is walk(d) -> compact(d) (which also spawns the rays of depth d+1) ->
+    // shadow walk(d) -> shade(d).  Only shade(d) needs shade(d-1) (it hands down the throughput); walk(d+1) and
+    // shadow walk(d) both need just compact(d).  With reflections the closest-hit chain therefore runs ahead
+    // on a second stream and the shadow walks of depth >= 1 on a third, so that the small, latency-bound
+    // launches of the deeper stages overlap the large shadow launch of depth 0 on the caller's stream, where
+    // all shading runs in order.  Buffers rotate (hit lists and shadow results by d & 1, queues by d % 3):
+    // compact(d + 2) is the first kernel to overwrite what shade(d) reads, and waits for it.
     const bool two_streams = depths > 1;
-    hipStream_t geo = stream;
+    hipStream_t geo = stream, deep = stream;
     if (two_streams) {
         if (!s->geometry_stream) HIP_TRY(hipStreamCreateWithFlags(&s->geometry_stream, hipStreamNonBlocking));
+        if (!s->deep_shadow_stream) HIP_TRY(hipStreamCreateWithFlags(&s->deep_shadow_stream, hipStreamNonBlocking));
         geo = s->geometry_stream;
-        while (s->sync.size() < (size_t)(2 * depths + 1)) {
+        deep = s->deep_shadow_stream;
+        while (s->sync.size() < (size_t)(3 * depths + 1)) {
             hipEvent_t e;
             HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             s->sync.push_back(e);
         }
     }
-    auto compacted = [&](int d) { return s->sync[(size_t)(1 + 2 * d)]; };
-    auto shaded = [&](int d) { return s->sync[(size_t)(2 + 2 * d)]; };
+    auto compacted = [&](int d) { return s->sync[(size_t)(1 + 3 * d)]; };
+    auto shaded = [&](int d) { return s->sync[(size_t)(2 + 3 * d)]; };
+    auto shadowed = [&](int d) { return s->sync[(size_t)(3 + 3 * d)]; };
     const bool deep_bg = p->background_deep[0] != 0.0f || p->background_deep[1] != 0.0f || p->background_deep[2] != 0.0f;
 
     HIP_TRY(hipMemsetAsync(s->ws_block, 0, 4096, stream));
@@ -450,7 +455,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
             }
             for (int d = 0; d < depths; ++d, ++stage) {
                 const bool spawn = d + 1 < depths;
-                // ---- geometry chain
+                // ---- closest hits
                 stream_of_launch = geo;
                 if ((rc = begin(0)) != RTAMD_OK) return rc;
                 launch_walk_closest(d == 0, count, s->ds, fc, s->ws, stage, d, geo);
@@ -459,17 +464,22 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
                 if ((rc = begin(2)) != RTAMD_OK) return rc;
                 launch_compact(d == 0, s->ds, fc, s->ws, stage, d, spawn, deep_bg && d > 0, rgb, face_id, t_hit, geo);
                 if ((rc = end()) != RTAMD_OK) return rc;
-                if (two_streams) {
-                    HIP_TRY(hipEventRecord(compacted(d), geo));
-                    HIP_TRY(hipStreamWaitEvent(stream, compacted(d), 0));
-                }
-                // ---- lighting chain
-                stream_of_launch = stream;
+                if (two_streams) HIP_TRY(hipEventRecord(compacted(d), geo));
+                // ---- shadow rays: depth 0 on the caller's stream, deeper ones beside it
+                hipStream_t sh = d == 0 ? stream : deep;
+                if (two_streams) HIP_TRY(hipStreamWaitEvent(sh, compacted(d), 0));
                 if (nshadow > 0) {
+                    stream_of_launch = sh;
                     if ((rc = begin(1)) != RTAMD_OK) return rc;
-                    launch_walk_shadow(count, s->ds, fc, s->ws, stage, d, stream);
+                    launch_walk_shadow(count, s->ds, fc, s->ws, stage, d, sh);
                     if ((rc = end()) != RTAMD_OK) return rc;
                 }
+                if (two_streams && d > 0) {
+                    HIP_TRY(hipEventRecord(shadowed(d), deep));
+                    HIP_TRY(hipStreamWaitEvent(stream, shadowed(d), 0));
+                }
+                // ---- shading, in depth order
+                stream_of_launch = stream;
                 if ((rc = begin(3)) != RTAMD_OK) return rc;
                 launch_shade(d == 0, s->ds, fc, s->ws, stage, d, spawn, rgb, stream);
                 if (deep_bg && d > 0) launch_misses(fc, s->ws, stage, d, rgb, stream);

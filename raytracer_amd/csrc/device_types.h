@@ -64,7 +64,7 @@ struct Workspace {
     int32_t *slot_tri; // TriRecord index, -1 sphere, -2 miss
     float *slot_t;     // hit distance
     HitList hits[2];   // by depth & 1
-    uint8_t *clear;    // [lights*samples][capacity]: 1 = the shadow ray of that sample is unoccluded
+    uint8_t *clear[2]; // by depth & 1: [lights*samples][capacity], 1 = the shadow ray of that sample is unoccluded
     // ray queues, rotating by depth % 3; 10 planes of `capacity` each: o.xyz, d.xyz, throughput.rgb, pixel(bits).
     // Geometry and pixel are written when the ray is spawned (compaction kernel of the parent depth), the
     // throughput later by the shading kernel of the parent depth.

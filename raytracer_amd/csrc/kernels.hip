@@ -398,7 +398,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
         }
 
         if (ANY) {
-            ws.clear[out_index] = best_tri == -2 ? 1 : 0;
+            ws.clear[depth & 1][out_index] = best_tri == -2 ? 1 : 0;
         } else {
             ws.slot_tri[out_index] = best_tri;
             ws.slot_t[out_index] = tbest;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, FrameConst f
     float li = 0.0f;
     for (int l = 0; l < sc.num_lights; ++l) {
         float reaching = 0.0f;
-        for (int k = 0; k < sc.spl; ++k) reaching += (float)ws.clear[(size_t)(l * sc.spl + k) * ws.capacity + idx];
+        for (int k = 0; k < sc.spl; ++k) reaching += (float)ws.clear[depth & 1][(size_t)(l * sc.spl + k) * ws.capacity + idx];
         li += reaching / (float)sc.spl;
     }
     li = smin(li, 1.0f);
