@@ -135,7 +135,7 @@ typedef struct {
 typedef struct {
     int32_t num_faces;        /* faces given                                                      */
     int32_t num_device_faces; /* faces in the device BVH (zero-area faces are left out)           */
-    int32_t num_nodes;        /* 64-byte inner nodes                                              */
+    int32_t num_nodes;        /* 128-byte inner nodes (up to four children each)                  */
     int32_t num_leaves;
     int32_t depth;
     int32_t device;           /* HIP device ordinal                                               */
@@ -152,7 +152,7 @@ void rtamd_camera_default(rtamd_camera *cam, int32_t width, int32_t height);
 void rtamd_render_params_default(rtamd_render_params *p, int32_t width, int32_t height);
 
 /* Replaces the tail of Flyscene::initialize (src/flyscene.cpp:116-134): takes the flattened scene,
- * builds the 64-byte-node BVH that stands in for boundingBox::splitBox (src/boundingBox.h:69-194)
+ * builds the four-way BVH that stands in for boundingBox::splitBox (src/boundingBox.h:69-194)
  * and uploads everything to the current HIP device. */
 int rtamd_scene_create(const rtamd_scene_desc *desc, const rtamd_build_params *build, rtamd_scene **out);
 int rtamd_scene_destroy(rtamd_scene *scene);

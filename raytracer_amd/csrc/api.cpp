@@ -238,9 +238,11 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     reference_face_rank(mesh, rank);
     FlatBvh bvh;
     build_flat_bvh(mesh, rank, build ? build->max_leaf_faces : 0, build ? build->sah_bins : 0, bvh);
-    if (bvh.depth > kStackEntries) {
+    // The walk keeps at most stack_need entries; narrower nodes need fewer (a binary tree needs its depth).
+    for (int width = 3; bvh.stack_need > kStackEntries && width >= 2; --width) collapse_bvh(bvh, width);
+    if (bvh.stack_need > kStackEntries) {
         delete s;
-        return fail(RTAMD_ERR_LIMIT, "BVH depth %d exceeds the traversal stack (%d)", bvh.depth, kStackEntries);
+        return fail(RTAMD_ERR_LIMIT, "BVH needs %d traversal stack entries, the kernels hold %d", bvh.stack_need, kStackEntries);
     }
     std::vector<ShadeRecord> shade((size_t)d->num_faces);
     for (int32_t f = 0; f < d->num_faces; ++f) {
@@ -271,7 +273,7 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     std::vector<float> lpos(d->light_positions, d->light_positions + 3 * (size_t)d->num_lights);
     std::vector<float> samples(d->light_samples, d->light_samples + 3 * (size_t)d->num_lights * d->samples_per_light);
     std::vector<rtamd_sphere> spheres(d->spheres, d->spheres + d->num_spheres);
-    if (rc == RTAMD_OK) rc = upload(&s->d_nodes, bvh.nodes, &bytes);
+    if (rc == RTAMD_OK) rc = upload(&s->d_nodes, bvh.nodes4, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_tris, bvh.tris, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_shade, shade, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_materials, mats, &bytes);
@@ -299,9 +301,9 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
 
     s->info.num_faces = d->num_faces;
     s->info.num_device_faces = bvh.num_device_faces;
-    s->info.num_nodes = (int32_t)bvh.nodes.size();
+    s->info.num_nodes = (int32_t)bvh.nodes4.size();
     s->info.num_leaves = bvh.num_leaves;
-    s->info.depth = bvh.depth;
+    s->info.depth = bvh.depth4;
     s->info.device = dev;
     s->info.device_bytes = bytes;
     s->info.build_ms = (float)(t1 - t0);
@@ -424,11 +426,18 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     // launches of the deeper stages overlap the large shadow launch of depth 0 on the caller's stream, where
     // all shading runs in order.  Buffers rotate (hit lists and shadow results by d & 1, queues by d % 3):
     // compact(d + 2) is the first kernel to overwrite what shade(d) reads, and waits for it.
-    const bool two_streams = depths > 1;
+    static const bool serial = getenv("RTAMD_SERIAL") != nullptr; // experiment hook: everything on the caller's stream
+    const bool two_streams = depths > 1 && !serial;
     hipStream_t geo = stream, deep = stream;
     if (two_streams) {
-        if (!s->geometry_stream) HIP_TRY(hipStreamCreateWithFlags(&s->geometry_stream, hipStreamNonBlocking));
-        if (!s->deep_shadow_stream) HIP_TRY(hipStreamCreateWithFlags(&s->deep_shadow_stream, hipStreamNonBlocking));
+        // The side chains are the critical path of the frame (few rays, long dependent chains): their waves get
+        // dispatch priority over the large depth-0 shadow launch they overlap.
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        static const bool flat = getenv("RTAMD_FLAT_PRIORITY") != nullptr; // experiment hook
+        const int prio = flat ? least : greatest;
+        if (!s->geometry_stream) HIP_TRY(hipStreamCreateWithPriority(&s->geometry_stream, hipStreamNonBlocking, prio));
+        if (!s->deep_shadow_stream) HIP_TRY(hipStreamCreateWithPriority(&s->deep_shadow_stream, hipStreamNonBlocking, prio));
         geo = s->geometry_stream;
         deep = s->deep_shadow_stream;
         while (s->sync.size() < (size_t)(3 * depths + 1)) {

@@ -318,6 +318,78 @@ void build_flat_bvh(const MeshView &mesh, const std::vector<int32_t> &rank, int 
         out.nodes.insert(out.nodes.begin(), nd);
         out.depth = std::max(out.depth, 1);
     }
+    collapse_bvh(out, 4);
+}
+
+namespace {
+
+struct Collapser {
+    FlatBvh &b;
+    int max_children;
+
+    struct Slot {
+        int32_t ref;
+        float lo[3], hi[3];
+        float half_area() const {
+            const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+            return dx * dy + dy * dz + dz * dx;
+        }
+    };
+
+    static Slot slot_of(const BvhNode &n, int k) {
+        Slot s;
+        s.ref = n.child[k];
+        s.lo[0] = n.x[2 * k], s.hi[0] = n.x[2 * k + 1];
+        s.lo[1] = n.y[2 * k], s.hi[1] = n.y[2 * k + 1];
+        s.lo[2] = n.z[2 * k], s.hi[2] = n.z[2 * k + 1];
+        return s;
+    }
+
+    // `held` = stack entries a walk may already hold when it arrives at this node
+    int32_t run(int32_t n2, int depth, int held) {
+        Slot c[4];
+        int k = 2;
+        c[0] = slot_of(b.nodes[(size_t)n2], 0);
+        c[1] = slot_of(b.nodes[(size_t)n2], 1);
+        while (k < max_children) {
+            int pick = -1;
+            float area = -1.0f;
+            for (int i = 0; i < k; ++i)
+                if (c[i].ref >= 0 && c[i].half_area() > area) area = c[i].half_area(), pick = i;
+            if (pick < 0) break;
+            const BvhNode &m = b.nodes[(size_t)c[pick].ref];
+            c[pick] = slot_of(m, 0);
+            c[k++] = slot_of(m, 1);
+        }
+        const int32_t me = (int32_t)b.nodes4.size();
+        b.nodes4.emplace_back();
+        b.depth4 = std::max(b.depth4, depth + 1);
+        b.stack_need = std::max(b.stack_need, held + k - 1);
+        int32_t refs[4];
+        for (int i = 0; i < k; ++i) refs[i] = c[i].ref >= 0 ? run(c[i].ref, depth + 1, held + k - 1) : c[i].ref;
+        Bvh4Node &nd = b.nodes4[(size_t)me];
+        std::memset(&nd, 0, sizeof nd);
+        nd.num_children = k;
+        for (int i = 0; i < 4; ++i) {
+            const bool used = i < k;
+            nd.lox[i] = used ? c[i].lo[0] : FLT_MAX, nd.hix[i] = used ? c[i].hi[0] : -FLT_MAX;
+            nd.loy[i] = used ? c[i].lo[1] : FLT_MAX, nd.hiy[i] = used ? c[i].hi[1] : -FLT_MAX;
+            nd.loz[i] = used ? c[i].lo[2] : FLT_MAX, nd.hiz[i] = used ? c[i].hi[2] : -FLT_MAX;
+            nd.child[i] = used ? refs[i] : ~0;
+        }
+        return me;
+    }
+};
+
+} // namespace
+
+void collapse_bvh(FlatBvh &bvh, int max_children) {
+    bvh.nodes4.clear();
+    bvh.depth4 = 0;
+    bvh.stack_need = 0;
+    bvh.nodes4.reserve(bvh.nodes.size() / 2 + 2);
+    Collapser c{bvh, std::min(std::max(max_children, 2), 4)};
+    c.run(0, 0, 0);
 }
 
 } // namespace rtamd

@@ -1,9 +1,10 @@
 // Host-side BVH construction for the gfx950 render pass.
 //
 // The reference keeps a tree of heavyweight boundingBox objects (src/boundingBox.h:25-316) and
-// visits every leaf a ray's boxes overlap.  Here the hierarchy is a flat array of 64-byte nodes,
-// each holding BOTH children's boxes so that one cache line decides the next step, plus a
-// leaf-contiguous array of 64-byte triangle records.  The tree itself is a binned-SAH tree: because
+// visits every leaf a ray's boxes overlap.  Here the hierarchy is a flat array of 128-byte nodes,
+// each holding the boxes of up to FOUR children so that one fetch decides the next step and the chain
+// of dependent fetches per ray is half as long as in a binary tree, plus a leaf-contiguous array of
+// 64-byte triangle records.  The tree is a binned-SAH binary tree collapsed to four-way: because
 // the reference's walk is exhaustive, any conservative hierarchy yields the same closest hit; the
 // only order-dependent rule of the reference (equal distances: the face met later wins,
 // src/flyscene.cpp:760,782-789) is carried as an explicit per-face rank, computed by replaying
@@ -22,6 +23,18 @@ struct alignas(64) BvhNode {
     float z[4];
     int32_t child[2];
     int32_t pad[2];
+};
+
+// 128 B, the device node.  Children's boxes as structure of arrays; child as in BvhNode.  Unused slots
+// hold an inverted box (lo = +FLT_MAX, hi = -FLT_MAX), which the sign-ordered slab test never enters,
+// and the reference of a leaf without records.
+struct alignas(128) Bvh4Node {
+    float lox[4], hix[4];
+    float loy[4], hiy[4];
+    float loz[4], hiz[4];
+    int32_t child[4];
+    int32_t num_children;
+    int32_t pad[3];
 };
 
 // 64 B.  What triangleIntersection reads per face (src/flyscene.cpp:752-789), gathered once.
@@ -46,13 +59,16 @@ struct alignas(32) ShadeRecord {
 };
 
 constexpr int kMaxLeafFaces = 15;
-constexpr int kMaxTreeDepth = 32; // = the traversal stack entries the kernels reserve per lane
+constexpr int kMaxTreeDepth = 32; // of the binary tree
 
 struct FlatBvh {
-    std::vector<BvhNode> nodes; // nodes[0] is the root
+    std::vector<BvhNode> nodes;   // binary tree, nodes[0] is the root (host only)
+    std::vector<Bvh4Node> nodes4; // what the kernels walk, nodes4[0] is the root
     std::vector<TriRecord> tris;
     int num_leaves = 0;
-    int depth = 0;
+    int depth = 0;      // binary tree
+    int depth4 = 0;     // collapsed tree
+    int stack_need = 0; // most entries a depth-first walk of nodes4 can hold at once
     int num_device_faces = 0;
 };
 
@@ -72,5 +88,9 @@ void reference_face_rank(const MeshView &mesh, std::vector<int32_t> &rank);
 
 // Binned-SAH build over the faces whose stored normal is finite and non-zero.
 void build_flat_bvh(const MeshView &mesh, const std::vector<int32_t> &rank, int max_leaf_faces, int sah_bins, FlatBvh &out);
+
+// nodes -> nodes4 with at most `max_children` (2..4) children per node: repeatedly replaces the inner
+// child of largest surface area by its two children.  Fills depth4 and stack_need.
+void collapse_bvh(FlatBvh &bvh, int max_children);
 
 } // namespace rtamd

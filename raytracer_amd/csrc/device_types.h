@@ -4,13 +4,13 @@
 
 namespace rtamd {
 
-constexpr int kStackEntries = 32;   // per-lane traversal stack (LDS + private memory); the builder bounds the tree depth to this
+constexpr int kStackEntries = 64;   // per-lane traversal stack (LDS + private memory); scene creation checks the tree against it
 constexpr int kMaxShadowRays = 512; // lights * samples_per_light per hit
 constexpr int kMaxStages = 64;      // (ssaa passes) * (max_reflections + 1) counter slots per frame
 
 // Read-only scene in HBM.
 struct DeviceScene {
-    const float4 *nodes;      // 4 x float4 per BvhNode
+    const float4 *nodes;      // 8 x float4 per Bvh4Node
     const float4 *tris;       // 4 x float4 per TriRecord
     const float4 *shade;      // 6 x float4 per ShadeRecord, indexed by face
     const float *materials;   // 10 floats per material: ka, kd, ks, shininess

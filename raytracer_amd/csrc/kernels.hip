@@ -199,6 +199,13 @@ __device__ __forceinline__ int stack_read(const int *stack, const int *deep, int
     return v;
 }
 
+__device__ __forceinline__ void stack_write(int *stack, int *deep, int sp, int v) {
+    if (sp < kLdsStack)
+        stack[sp * 64] = v;
+    else
+        deep[sp - kLdsStack] = v;
+}
+
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth, int total_static) {
     __shared__ int s_stack[(kLdsStack + kLeafQueue) * 64];
@@ -312,44 +319,68 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
                     }
                     continue;
                 }
-                const float4 nx = sc.nodes[node * 4 + 0];
-                const float4 ny = sc.nodes[node * 4 + 1];
-                const float4 nz = sc.nodes[node * 4 + 2];
-                const float4 nc = sc.nodes[node * 4 + 3];
-                if (COUNT) w_box += 2;
-                // per axis the node holds (child0.min, child0.max, child1.min, child1.max)
-                const float n0x = __builtin_fmaf(negx ? nx.y : nx.x, ix, bnx), f0x = __builtin_fmaf(negx ? nx.x : nx.y, ix, bfx);
-                const float n0y = __builtin_fmaf(negy ? ny.y : ny.x, iy, bny), f0y = __builtin_fmaf(negy ? ny.x : ny.y, iy, bfy);
-                const float n0z = __builtin_fmaf(negz ? nz.y : nz.x, iz, bnz), f0z = __builtin_fmaf(negz ? nz.x : nz.y, iz, bfz);
-                const float n1x = __builtin_fmaf(negx ? nx.w : nx.z, ix, bnx), f1x = __builtin_fmaf(negx ? nx.z : nx.w, ix, bfx);
-                const float n1y = __builtin_fmaf(negy ? ny.w : ny.z, iy, bny), f1y = __builtin_fmaf(negy ? ny.z : ny.w, iy, bfy);
-                const float n1z = __builtin_fmaf(negz ? nz.w : nz.z, iz, bnz), f1z = __builtin_fmaf(negz ? nz.z : nz.w, iz, bfz);
-                const float n0 = fmaxf(fmaxf(n0x, n0y), fmaxf(n0z, 0.0f));
-                const float f0 = fminf(fminf(f0x, f0y), fminf(f0z, tlimit));
-                const float n1 = fmaxf(fmaxf(n1x, n1y), fmaxf(n1z, 0.0f));
-                const float f1 = fminf(fminf(f1x, f1y), fminf(f1z, tlimit));
+                // four children per node: (lo, hi) of each axis as float4 over the children, then the references
+                const float4 *nd = sc.nodes + (size_t)node * 8;
+                const float4 lox = nd[0], hix = nd[1], loy = nd[2], hiy = nd[3], loz = nd[4], hiz = nd[5];
+                const float4 chf = nd[6];
+                if (COUNT) w_box += (unsigned)__float_as_int(nd[7].x);
+                const int c0 = __float_as_int(chf.x), c1 = __float_as_int(chf.y), c2 = __float_as_int(chf.z), c3 = __float_as_int(chf.w);
+                float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
+#define RT_SLAB(K, C)                                                                                                    \
+    tn##K = fmaxf(fmaxf(__builtin_fmaf(negx ? hix.C : lox.C, ix, bnx), __builtin_fmaf(negy ? hiy.C : loy.C, iy, bny)),  \
+                  fmaxf(__builtin_fmaf(negz ? hiz.C : loz.C, iz, bnz), 0.0f));                                           \
+    tf##K = fminf(fminf(__builtin_fmaf(negx ? lox.C : hix.C, ix, bfx), __builtin_fmaf(negy ? loy.C : hiy.C, iy, bfy)),  \
+                  fminf(__builtin_fmaf(negz ? loz.C : hiz.C, iz, bfz), tlimit));
+                RT_SLAB(0, x)
+                RT_SLAB(1, y)
+                RT_SLAB(2, z)
+                RT_SLAB(3, w)
+#undef RT_SLAB
                 // the factor covers the relative rounding of the distances themselves
-                const bool h0 = n0 <= f0 * 1.0000005f;
-                const bool h1 = n1 <= f1 * 1.0000005f;
-                const int c0i = __float_as_int(nc.x), c1i = __float_as_int(nc.y);
-                if (h0 && h1) {
-                    const bool first0 = n0 <= n1;
-                    const int far = first0 ? c1i : c0i;
-                    if (sp < kLdsStack)
-                        stack[sp * 64] = far;
-                    else
-                        deep[sp - kLdsStack] = far;
-                    ++sp;
-                    node = first0 ? c0i : c1i;
-                } else if (h0) {
-                    node = c0i;
-                } else if (h1) {
-                    node = c1i;
-                } else if (sp == 0) {
-                    node = kSentinel;
+                const bool h0 = tn0 <= tf0 * 1.0000005f, h1 = tn1 <= tf1 * 1.0000005f;
+                const bool h2 = tn2 <= tf2 * 1.0000005f, h3 = tn3 <= tf3 * 1.0000005f;
+                const int k1 = (int)h0, k2 = k1 + (int)h1, k3 = k2 + (int)h2, hits = k3 + (int)h3;
+                if (hits == 0) {
+                    if (sp == 0) {
+                        node = kSentinel;
+                    } else {
+                        --sp;
+                        node = stack_read(stack, deep, sp);
+                    }
+                } else if (ANY) {
+                    // any order will do: the first child that is hit is next, the others wait on the stack
+                    if (h1 && k1 > 0) stack_write(stack, deep, sp + k1 - 1, c1);
+                    if (h2 && k2 > 0) stack_write(stack, deep, sp + k2 - 1, c2);
+                    if (h3 && k3 > 0) stack_write(stack, deep, sp + k3 - 1, c3);
+                    node = h0 ? c0 : h1 ? c1 : h2 ? c2 : c3;
+                    sp += hits - 1;
                 } else {
-                    --sp;
-                    node = stack_read(stack, deep, sp);
+                    // nearest first: sort (entry distance, slot) keys -- distances are >= 0, so their bit
+                    // patterns order like integers; the two lowest mantissa bits carry the slot
+                    int s0 = h0 ? (__float_as_int(tn0) & ~3) | 0 : 0x7fffffff;
+                    int s1 = h1 ? (__float_as_int(tn1) & ~3) | 1 : 0x7fffffff;
+                    int s2 = h2 ? (__float_as_int(tn2) & ~3) | 2 : 0x7fffffff;
+                    int s3 = h3 ? (__float_as_int(tn3) & ~3) | 3 : 0x7fffffff;
+#define RT_CSWAP(A, B)            \
+    {                             \
+        const int lo_ = min(A, B); \
+        B = max(A, B);            \
+        A = lo_;                  \
+    }
+                    RT_CSWAP(s0, s1)
+                    RT_CSWAP(s2, s3)
+                    RT_CSWAP(s0, s2)
+                    RT_CSWAP(s1, s3)
+                    RT_CSWAP(s1, s2)
+#undef RT_CSWAP
+#define RT_REF(S) (((S)&2) ? (((S)&1) ? c3 : c2) : (((S)&1) ? c1 : c0))
+                    node = RT_REF(s0);
+                    // farthest deepest, so that the nearest of the rest is popped first
+                    if (hits > 1) stack_write(stack, deep, sp + hits - 2, RT_REF(s1));
+                    if (hits > 2) stack_write(stack, deep, sp + hits - 3, RT_REF(s2));
+                    if (hits > 3) stack_write(stack, deep, sp, RT_REF(s3));
+#undef RT_REF
+                    sp += hits - 1;
                 }
             }
             if (nq == 0) break; // nothing parked: the walk of this lane is over
