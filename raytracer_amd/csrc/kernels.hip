@@ -285,7 +285,9 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
         if (cx) ix = copysignf(kInvMax, d.x);
         if (cy) iy = copysignf(kInvMax, d.y);
         if (cz) iz = copysignf(kInvMax, d.z);
-        const bool negx = ix < 0.0f, negy = iy < 0.0f, negz = iz < 0.0f;
+        // byte offsets, inside a node, of the float4 holding the ENTRY bounds of each axis (lo for a positive
+        // direction, hi for a negative one); the exit bounds sit 16 bytes to the other side (offset ^ 16)
+        const unsigned offx = ix < 0.0f ? 16u : 0u, offy = iy < 0.0f ? 48u : 32u, offz = iz < 0.0f ? 80u : 64u;
         const float bx = -o.x * ix, by = -o.y * iy, bz = -o.z * iz;
         const float ex = cx ? 0.0f : 1.2e-7f * fabsf(bx), ey = cy ? 0.0f : 1.2e-7f * fabsf(by), ez = cz ? 0.0f : 1.2e-7f * fabsf(bz);
         const float bnx = bx - ex, bny = by - ey, bnz = bz - ez; // addends of entry distances
@@ -319,18 +321,20 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
                     }
                     continue;
                 }
-                // four children per node: (lo, hi) of each axis as float4 over the children, then the references
-                const float4 *nd = sc.nodes + (size_t)node * 8;
-                const float4 lox = nd[0], hix = nd[1], loy = nd[2], hiy = nd[3], loz = nd[4], hiz = nd[5];
-                const float4 chf = nd[6];
-                if (COUNT) w_box += (unsigned)__float_as_int(nd[7].x);
+                // four children per node: (lo, hi) of each axis as float4 over the children, then the references.
+                // Entry and exit bounds are picked by address, not by a select per value.
+                const char *nodes = (const char *)sc.nodes;
+                const unsigned nb = (unsigned)node << 7;
+                const float4 ex4 = *(const float4 *)(nodes + (nb + offx)), fx4 = *(const float4 *)(nodes + ((nb + offx) ^ 16u));
+                const float4 ey4 = *(const float4 *)(nodes + (nb + offy)), fy4 = *(const float4 *)(nodes + ((nb + offy) ^ 16u));
+                const float4 ez4 = *(const float4 *)(nodes + (nb + offz)), fz4 = *(const float4 *)(nodes + ((nb + offz) ^ 16u));
+                const float4 chf = *(const float4 *)(nodes + (nb + 96u));
+                if (COUNT) w_box += (unsigned)__float_as_int((*(const float4 *)(nodes + (nb + 112u))).x);
                 const int c0 = __float_as_int(chf.x), c1 = __float_as_int(chf.y), c2 = __float_as_int(chf.z), c3 = __float_as_int(chf.w);
                 float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
-#define RT_SLAB(K, C)                                                                                                    \
-    tn##K = fmaxf(fmaxf(__builtin_fmaf(negx ? hix.C : lox.C, ix, bnx), __builtin_fmaf(negy ? hiy.C : loy.C, iy, bny)),  \
-                  fmaxf(__builtin_fmaf(negz ? hiz.C : loz.C, iz, bnz), 0.0f));                                           \
-    tf##K = fminf(fminf(__builtin_fmaf(negx ? lox.C : hix.C, ix, bfx), __builtin_fmaf(negy ? loy.C : hiy.C, iy, bfy)),  \
-                  fminf(__builtin_fmaf(negz ? loz.C : hiz.C, iz, bfz), tlimit));
+#define RT_SLAB(K, C)                                                                                                           \
+    tn##K = fmaxf(fmaxf(__builtin_fmaf(ex4.C, ix, bnx), __builtin_fmaf(ey4.C, iy, bny)), fmaxf(__builtin_fmaf(ez4.C, iz, bnz), 0.0f)); \
+    tf##K = fminf(fminf(__builtin_fmaf(fx4.C, ix, bfx), __builtin_fmaf(fy4.C, iy, bfy)), fminf(__builtin_fmaf(fz4.C, iz, bfz), tlimit));
                 RT_SLAB(0, x)
                 RT_SLAB(1, y)
                 RT_SLAB(2, z)
