@@ -444,110 +444,131 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
 
 // ---------------------------------------------------------------------------------------------
 // Compaction: ray slots that hit something -> dense hit list (slot order inside a workgroup, one atomic
-// per workgroup and list).  Also writes the hit point, the primary planes (face id, distance), the colour
+// per workgroup and list: atomics on one address serialise in L2, so a workgroup covers up to 2048 slots).  Also writes the hit point, the primary planes (face id, distance), the colour
 // of primary rays that hit nothing (src/flyscene.cpp:650-658), and -- the reflection set-up of traceRay,
 // src/flyscene.cpp:617-646 -- geometry and pixel of the reflection ray into the next queue.  The ray's
 // throughput needs the light intensity and is filled in later by the shading kernel, through `child`.
 // ---------------------------------------------------------------------------------------------
-template <bool PRIMARY>
+// kCompactSegments = 256-slot segments per workgroup (one atomic per list and workgroup): many for large
+// images, where the atomics would dominate, few for small ones, which need the workgroups to fill the chip.
+template <bool PRIMARY, int kCompactSegments>
 __global__ __launch_bounds__(256) void compact_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth, int spawn, int list_misses,
                                                       float *rgb, int32_t *face_id, float *t_hit, int total_static) {
-    __shared__ int s_count[3][4];
+    __shared__ int s_count[3][kCompactSegments][4]; // list (hits, spawned rays, misses) x segment x wave
     __shared__ int s_base[3];
     const int total = PRIMARY ? total_static : ws.stage[stage - 1].next;
-    const int first = (int)blockIdx.x * 256;
+    const int first = (int)blockIdx.x * (256 * kCompactSegments);
     if (first >= total) return;
     const HitList hl = ws.hits[depth & 1];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slot = first + tid;
-    bool valid = slot < total;
-    int x = 0, row = 0;
-    if (PRIMARY && valid) valid = slot_pixel(fc, slot, x, row);
-    const int tri = valid ? ws.slot_tri[slot] : -2;
-    const bool hit = tri != -2;
-    const bool miss = list_misses && valid && !hit;
-    const float t = hit ? ws.slot_t[slot] : 0.0f;
 
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
-    int pix = 0;
-    if (PRIMARY) {
-        pix = row * fc.width + x;
-        if (valid) {
-            if (face_id) face_id[pix] = tri >= 0 ? __float_as_int(sc.tris[tri * 4 + 1].w) : tri;
-            if (t_hit) t_hit[pix] = t;
-            if (!hit) { // background of a primary ray, :653-658
-                float *p = rgb + 3 * (size_t)pix;
-                if (fc.accumulate) {
-                    p[0] += fc.bg[0], p[1] += fc.bg[1], p[2] += fc.bg[2];
-                } else {
-                    p[0] = fc.bg[0], p[1] = fc.bg[1], p[2] = fc.bg[2];
-                }
+    // ---- pass 1: classify the slots of every segment, count per wave
+    int tri_of[kCompactSegments];
+    unsigned hit_bits = 0, go_bits = 0, miss_bits = 0;
+#pragma unroll
+    for (int j = 0; j < kCompactSegments; ++j) {
+        const int slot = first + j * 256 + tid;
+        bool valid = slot < total;
+        if (PRIMARY && valid) {
+            int x, row;
+            valid = slot_pixel(fc, slot, x, row);
+        }
+        const int tri = valid ? ws.slot_tri[slot] : -2;
+        const bool hit = tri != -2;
+        const bool miss = list_misses && valid && !hit;
+        // does this hit reflect?  src/flyscene.cpp:617-632 (a sphere ends the path, :618-621)
+        bool go = false;
+        if (spawn && hit && tri >= 0) {
+            const int face = __float_as_int(sc.tris[tri * 4 + 1].w);
+            const int mat = __float_as_int(sc.shade[face * 6 + 5].y);
+            if (mat >= 0 && mat < sc.num_materials) {
+                const float *mp = sc.materials + 10 * mat;
+                go = mp[6] > fc.refl_thresh || mp[7] > fc.refl_thresh || mp[8] > fc.refl_thresh; // :631-632
             }
         }
-        o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
-        if (hit) d = primary_direction(fc, x, row);
-    } else if (hit) {
-        const float *q = ws.queue[depth % 3];
-        o = mk(plane(q, ws.capacity, 0)[slot], plane(q, ws.capacity, 1)[slot], plane(q, ws.capacity, 2)[slot]);
-        d = mk(plane(q, ws.capacity, 3)[slot], plane(q, ws.capacity, 4)[slot], plane(q, ws.capacity, 5)[slot]);
-        pix = __float_as_int(plane(q, ws.capacity, 9)[slot]);
-    }
-    const V3 hp = o + t * d; // hitPoint, :709,771
-
-    // does this hit reflect?  :617-632 (a sphere ends the path, :618-621)
-    bool go = false;
-    V3 fn = mk(0, 0, 1);
-    if (spawn && hit && tri >= 0) {
-        const int face = __float_as_int(sc.tris[tri * 4 + 1].w);
-        const float4 s4 = sc.shade[face * 6 + 4], s5 = sc.shade[face * 6 + 5];
-        const int mat = __float_as_int(s5.y);
-        if (mat >= 0 && mat < sc.num_materials) {
-            const float *mp = sc.materials + 10 * mat;
-            go = mp[6] > fc.refl_thresh || mp[7] > fc.refl_thresh || mp[8] > fc.refl_thresh; // :631-632
-            fn = mk(s4.z, s4.w, s5.x);
+        tri_of[j] = tri;
+        hit_bits |= (unsigned)hit << j, go_bits |= (unsigned)go << j, miss_bits |= (unsigned)miss << j;
+        const unsigned long long m_hit = __ballot(hit), m_go = __ballot(go), m_miss = __ballot(miss);
+        if (lane == 0) {
+            s_count[0][j][wave] = __popcll(m_hit);
+            s_count[1][j][wave] = __popcll(m_go);
+            s_count[2][j][wave] = __popcll(m_miss);
         }
-    }
-
-    const unsigned long long m_hit = __ballot(hit), m_go = __ballot(go), m_miss = __ballot(miss);
-    if (lane == 0) {
-        s_count[0][wave] = __popcll(m_hit);
-        s_count[1][wave] = __popcll(m_go);
-        s_count[2][wave] = __popcll(m_miss);
     }
     __syncthreads();
     if (tid < 3) {
-        const int n = s_count[tid][0] + s_count[tid][1] + s_count[tid][2] + s_count[tid][3];
+        int n = 0;
+        for (int j = 0; j < kCompactSegments; ++j) n += s_count[tid][j][0] + s_count[tid][j][1] + s_count[tid][j][2] + s_count[tid][j][3];
         int *counter = tid == 0 ? &ws.stage[stage].hits : tid == 1 ? &ws.stage[stage].next : &ws.stage[stage].misses;
         s_base[tid] = n ? atomicAdd(counter, n) : 0;
     }
     __syncthreads();
+
+    // ---- pass 2: write, segment by segment, wave by wave, lane by lane: slot order is kept inside the workgroup
     const unsigned long long below = (1ull << lane) - 1ull;
-    int child = -1;
-    if (go) {
-        int pos = s_base[1] + __popcll(m_go & below);
-        for (int w = 0; w < wave; ++w) pos += s_count[1][w];
-        child = pos;
-        const V3 refl = normalized(d - (2 * dot(d, fn)) * fn); // :785 then :635
-        const V3 no = hp + fc.bounce_off * refl;               // :636
-        float *q = ws.queue[(depth + 1) % 3];
-        plane(q, ws.capacity, 0)[pos] = no.x, plane(q, ws.capacity, 1)[pos] = no.y, plane(q, ws.capacity, 2)[pos] = no.z;
-        plane(q, ws.capacity, 3)[pos] = refl.x, plane(q, ws.capacity, 4)[pos] = refl.y, plane(q, ws.capacity, 5)[pos] = refl.z;
-        plane(q, ws.capacity, 9)[pos] = __int_as_float(pix);
-    }
-    if (hit) {
-        int pos = s_base[0] + __popcll(m_hit & below);
-        for (int w = 0; w < wave; ++w) pos += s_count[0][w];
-        hl.slot[pos] = slot;
-        hl.tri[pos] = tri;
-        if (spawn) hl.child[pos] = child;
-        plane(hl.p, ws.capacity, 0)[pos] = hp.x;
-        plane(hl.p, ws.capacity, 1)[pos] = hp.y;
-        plane(hl.p, ws.capacity, 2)[pos] = hp.z;
-    }
-    if (miss) {
-        int pos = s_base[2] + __popcll(m_miss & below);
-        for (int w = 0; w < wave; ++w) pos += s_count[2][w];
-        hl.slot[ws.capacity - 1 - pos] = slot; // hits + misses <= rays <= capacity: the two ends never meet
+    int run_hit = s_base[0], run_go = s_base[1], run_miss = s_base[2];
+#pragma unroll
+    for (int j = 0; j < kCompactSegments; ++j) {
+        const int slot = first + j * 256 + tid;
+        const int tri = tri_of[j];
+        const bool hit = (hit_bits >> j) & 1u, go = (go_bits >> j) & 1u, miss = (miss_bits >> j) & 1u;
+        const unsigned long long m_hit = __ballot(hit), m_go = __ballot(go), m_miss = __ballot(miss);
+        int pos_hit = run_hit, pos_go = run_go, pos_miss = run_miss;
+        for (int w = 0; w < 4; ++w) {
+            const int ch = s_count[0][j][w], cg = s_count[1][j][w], cm = s_count[2][j][w];
+            if (w < wave) pos_hit += ch, pos_go += cg, pos_miss += cm;
+            run_hit += ch, run_go += cg, run_miss += cm;
+        }
+        pos_hit += __popcll(m_hit & below), pos_go += __popcll(m_go & below), pos_miss += __popcll(m_miss & below);
+
+        const float t = hit ? ws.slot_t[slot] : 0.0f;
+        V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+        int pix = 0;
+        if (PRIMARY) {
+            int x = 0, row = 0;
+            const bool valid = slot < total && slot_pixel(fc, slot, x, row);
+            pix = row * fc.width + x;
+            if (valid) {
+                if (face_id) face_id[pix] = tri >= 0 ? __float_as_int(sc.tris[tri * 4 + 1].w) : tri;
+                if (t_hit) t_hit[pix] = t;
+                if (!hit) { // background of a primary ray, :653-658
+                    float *p = rgb + 3 * (size_t)pix;
+                    if (fc.accumulate) {
+                        p[0] += fc.bg[0], p[1] += fc.bg[1], p[2] += fc.bg[2];
+                    } else {
+                        p[0] = fc.bg[0], p[1] = fc.bg[1], p[2] = fc.bg[2];
+                    }
+                }
+            }
+            o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
+            if (hit) d = primary_direction(fc, x, row);
+        } else if (hit) {
+            const float *q = ws.queue[depth % 3];
+            o = mk(plane(q, ws.capacity, 0)[slot], plane(q, ws.capacity, 1)[slot], plane(q, ws.capacity, 2)[slot]);
+            d = mk(plane(q, ws.capacity, 3)[slot], plane(q, ws.capacity, 4)[slot], plane(q, ws.capacity, 5)[slot]);
+            pix = __float_as_int(plane(q, ws.capacity, 9)[slot]);
+        }
+        const V3 hp = o + t * d; // hitPoint, :709,771
+        if (go) {
+            const int face = __float_as_int(sc.tris[tri * 4 + 1].w);
+            const float4 s4 = sc.shade[face * 6 + 4], s5 = sc.shade[face * 6 + 5];
+            const V3 fn = mk(s4.z, s4.w, s5.x);
+            const V3 refl = normalized(d - (2 * dot(d, fn)) * fn); // :785 then :635
+            const V3 no = hp + fc.bounce_off * refl;               // :636
+            float *q = ws.queue[(depth + 1) % 3];
+            plane(q, ws.capacity, 0)[pos_go] = no.x, plane(q, ws.capacity, 1)[pos_go] = no.y, plane(q, ws.capacity, 2)[pos_go] = no.z;
+            plane(q, ws.capacity, 3)[pos_go] = refl.x, plane(q, ws.capacity, 4)[pos_go] = refl.y, plane(q, ws.capacity, 5)[pos_go] = refl.z;
+            plane(q, ws.capacity, 9)[pos_go] = __int_as_float(pix);
+        }
+        if (hit) {
+            hl.slot[pos_hit] = slot;
+            hl.tri[pos_hit] = tri;
+            if (spawn) hl.child[pos_hit] = go ? pos_go : -1;
+            plane(hl.p, ws.capacity, 0)[pos_hit] = hp.x;
+            plane(hl.p, ws.capacity, 1)[pos_hit] = hp.y;
+            plane(hl.p, ws.capacity, 2)[pos_hit] = hp.z;
+        }
+        if (miss) hl.slot[ws.capacity - 1 - pos_miss] = slot; // hits + misses <= rays <= capacity: the two ends never meet
     }
 }
 
@@ -732,10 +753,21 @@ void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const 
 void launch_compact(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, bool spawn,
                     bool list_misses, float *rgb, int32_t *face_id, float *t_hit, hipStream_t stream) {
     const int total_static = fc.tiles_x * fc.tiles_y * 64;
-    if (primary)
-        compact_kernel<true><<<(total_static + 255) / 256, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, 0, rgb, face_id, t_hit, total_static);
-    else
-        compact_kernel<false><<<(ws.capacity + 255) / 256, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, list_misses, rgb, face_id, t_hit, 0);
+    const int slots = primary ? total_static : ws.capacity;
+    const bool large = slots > (4 << 20);
+    const int per_block = 256 * (large ? 8 : 2);
+    const int blocks = (slots + per_block - 1) / per_block;
+    if (primary) {
+        if (large)
+            compact_kernel<true, 8><<<blocks, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, 0, rgb, face_id, t_hit, total_static);
+        else
+            compact_kernel<true, 2><<<blocks, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, 0, rgb, face_id, t_hit, total_static);
+    } else {
+        if (large)
+            compact_kernel<false, 8><<<blocks, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, list_misses, rgb, face_id, t_hit, 0);
+        else
+            compact_kernel<false, 2><<<blocks, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, list_misses, rgb, face_id, t_hit, 0);
+    }
 }
 
 void launch_walk_shadow(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, hipStream_t stream) {
