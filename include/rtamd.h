@@ -49,6 +49,14 @@ typedef struct {
     float radius;
 } rtamd_sphere;
 
+/* One entry of Flyscene::texturedatas (src/flyscene.hpp:187, filled at src/flyscene.cpp:52-71): the
+ * texels of a material's map_kd image as ImageImporter::loadPPMImageData returns them
+ * (utils/ppmIO.hpp:36-86): value / maximum, rows flipped, so row 0 is the LAST row of the file. */
+typedef struct {
+    int32_t width, height;
+    const float *rgb; /* width*height*3 */
+} rtamd_texture;
+
 /* struct PrecomputedData (src/defs.h:7-20) plus what shadeOffFace/getLightIntensity read beside
  * it: materials (src/flyscene.hpp:181), lights (src/flyscene.hpp:163) and spheres (:166). */
 typedef struct {
@@ -69,6 +77,11 @@ typedef struct {
     int32_t samples_per_light;
     const rtamd_sphere *spheres;
     int32_t num_spheres;
+    /* Texture branch of shadeOffFace (src/flyscene.cpp:476-481,516-542); all three may be NULL / 0. */
+    const float *face_texcoords;       /* num_faces*6: (u,v) of the three corners, Mesh::Face::texcoord  */
+    const int32_t *material_textures;  /* num_materials: index into textures, -1 = material has no map_kd */
+    const rtamd_texture *textures;
+    int32_t num_textures;
 } rtamd_scene_desc;
 
 typedef struct {
@@ -88,6 +101,10 @@ typedef struct {
 
 #define RTAMD_FLAG_COUNT_WORK 1u /* also count box tests / triangle tests (slower kernels)        */
 #define RTAMD_FLAG_TIME_KERNELS 2u /* bracket every launch with HIP events on the render stream   */
+/* Frames with reflections overlap their deeper stages with the depth-0 shadow rays on two internal,
+ * process-wide side streams.  A process whose streams already outnumber its hardware queues
+ * (GPU_MAX_HW_QUEUES, four by default) should set this flag: everything then runs on the caller's stream. */
+#define RTAMD_FLAG_SINGLE_STREAM 4u
 
 /* The compile-time macros of src/flyscene.hpp:22-41 and the literals of src/flyscene.cpp as
  * run-time fields, plus the row-tile partition used for multi-GPU rendering. */

@@ -28,6 +28,11 @@ int rtfly_set_model(rtfly *f, const char *obj_path);     /* default "resources/m
 int rtfly_set_model_arrays(rtfly *f, const float *vertices, const float *normals, int32_t num_vertices,
                            const int32_t *faces, const int32_t *face_material, int32_t num_faces,
                            const rtamd_material *materials, int32_t num_materials);
+/* Textures for a mesh given as arrays (after rtfly_set_model_arrays): what the OBJ path derives from `vt`,
+ * `map_kd` and the PPM files (utils/objimporter.hpp:51-79; utils/mtlIO.hpp:122-125; src/flyscene.cpp:52-71).
+ * face_texcoords = num_faces*6; material_textures = num_materials indices into textures, -1 = none. */
+int rtfly_set_texture_arrays(rtfly *f, const float *face_texcoords, const int32_t *material_textures,
+                             const rtamd_texture *textures, int32_t num_textures);
 int rtfly_clear_lights(rtfly *f);                        /* drop the default light (-1,1,1)         */
 int rtfly_add_light_at(rtfly *f, const float *position, const float *color);
 int rtfly_set_shadow_sampling(rtfly *f, int32_t hard_shadow, int32_t soft_points, float soft_radius);

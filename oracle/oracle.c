@@ -40,7 +40,14 @@ typedef struct orc_node {
 typedef struct {
     char name[256];
     orc_material m;
+    char tex_file[1024]; /* Mtl::diffuse_tex_filename, "" = none */
 } named_material;
+
+typedef struct {
+    int w, h;
+    float *rgb;          /* texturedatas[filename]: w*h*3, rows flipped as loadPPMImageData leaves them */
+    char file[1024];
+} orc_tex;
 
 struct orc_scene {
     /* S1: mesh as Tucano::Mesh holds it */
@@ -50,6 +57,10 @@ struct orc_scene {
     int *fvid;     /* nf*3 */
     float *fnormal; /* nf*3 Face::normal, mesh.hpp:475-477 */
     int *fmat;     /* nf */
+    float *ftex;   /* nf*6 Face::texcoord (u,v per corner), NULL when the mesh has no texture coordinates */
+    int ntex;
+    orc_tex *tex;
+    int *mat_tex;  /* nmat: index into tex, -1 = material without map_kd */
     int nmat;
     named_material *mats;
     orc_material *mats_plain;
@@ -167,7 +178,19 @@ static int load_mtl(const char *filename, named_material **mats, int *nmat) {
             } else if (strcmp(tok[0], "Ks") == 0) {
                 m->ks[0] = (float)atof(t1), m->ks[1] = (float)atof(t2), m->ks[2] = (float)atof(t3);
             }
-            /* Ni, d, illum, map_kd: not read on the traced path (texture branch not restated) */
+            else if (strcmp(tok[0], "map_kd") == 0) { /* lower case only, mtlIO.hpp:122-125 */
+                char dir[1024];
+                const char *a = strrchr(filename, '/');
+                const char *b = strrchr(filename, '\\');
+                const char *cut = a > b ? a : b;
+                size_t dl = cut ? (size_t)(cut - filename) + 1 : 0;
+                if (dl >= sizeof dir) dl = sizeof dir - 1;
+                memcpy(dir, filename, dl);
+                dir[dl] = 0;
+                named_material *nm = &(*mats)[*nmat - 1];
+                snprintf(nm->tex_file, sizeof nm->tex_file, "%s%s", dir, t1);
+            }
+            /* Ni, d, illum: not read on the traced path */
         }
     }
     free(line);
@@ -179,6 +202,67 @@ static int load_mtl(const char *filename, named_material **mats, int *nmat) {
         *nmat = 1;
     }
     return 1;
+}
+
+/* ---------------------------------- texture (PPM) reading ---------------------------------- */
+
+/* ImageImporter::loadPPMImageData, ppmIO.hpp:36-86: header word, width, height, maximum, then
+ * value/maximum for every number, rows flipped.  Returns 0 when the file cannot be read as that (the
+ * reference then indexes empty vectors). */
+static int load_ppm_texture(const char *filename, orc_tex *t) {
+    char fn[1024];
+    snprintf(fn, sizeof fn, "%s", filename);
+    strip_crlf(fn); /* :40-41 */
+    memset(t, 0, sizeof *t);
+    snprintf(t->file, sizeof t->file, "%s", fn);
+    FILE *in = fopen(fn, "r");
+    if (!in) {
+        fprintf(stderr, "Cannot open %s\n", fn);
+        return 0;
+    }
+    char header[64];
+    float maxv = 0;
+    int ok = fscanf(in, "%63s", header) == 1 && fscanf(in, "%d %d", &t->w, &t->h) == 2 && fscanf(in, "%f", &maxv) == 1;
+    if (!ok || t->w <= 0 || t->h <= 0) {
+        fclose(in);
+        t->w = t->h = 0;
+        return 0;
+    }
+    const size_t n = (size_t)t->w * (size_t)t->h * 3;
+    float *data = (float *)malloc(n * sizeof(float));
+    size_t got = 0;
+    float v;
+    while (got < n && fscanf(in, "%f", &v) == 1) data[got++] = v / maxv; /* :57-60 */
+    fclose(in);
+    if (got < n) {
+        free(data);
+        t->w = t->h = 0;
+        return 0;
+    }
+    t->rgb = (float *)malloc(n * sizeof(float));
+    for (int j = t->h - 1, r = 0; j >= 0; --j, ++r) /* :68-77 */
+        memcpy(t->rgb + (size_t)r * t->w * 3, data + (size_t)j * t->w * 3, (size_t)t->w * 3 * sizeof(float));
+    free(data);
+    return 1;
+}
+
+/* Flyscene::initialize, flyscene.cpp:52-71: one texture per distinct file name (std::map::insert keeps the
+ * first); mat_tex[i] = its index. */
+static void load_material_textures(orc_scene *s) {
+    s->mat_tex = (int *)malloc((size_t)(s->nmat > 0 ? s->nmat : 1) * sizeof(int));
+    for (int i = 0; i < s->nmat; ++i) {
+        s->mat_tex[i] = -1;
+        if (!s->mats[i].tex_file[0]) continue;
+        char fn[1024];
+        snprintf(fn, sizeof fn, "%s", s->mats[i].tex_file);
+        strip_crlf(fn);
+        for (int k = 0; k < s->ntex; ++k)
+            if (strcmp(s->tex[k].file, fn) == 0) s->mat_tex[i] = k;
+        if (s->mat_tex[i] >= 0) continue;
+        s->tex = (orc_tex *)realloc(s->tex, (size_t)(s->ntex + 1) * sizeof(orc_tex));
+        load_ppm_texture(fn, &s->tex[s->ntex]);
+        s->mat_tex[i] = s->ntex++;
+    }
 }
 
 /* ------------------------------------ S1: OBJ reading ------------------------------------- */
@@ -239,9 +323,11 @@ orc_scene *orc_scene_load_obj(const char *path) {
     dirname_of(path, dir, sizeof dir);
 
     fvec vert = {0}, norm = {0};
+    fvec vt = {0}; /* pushed three at a time: (u, v, 0) */
     /* groups: one index list per usemtl block, objimporter.hpp:144-148,168-177 */
     int ngroups = 1, gcap = 8;
     ivec *groups = (ivec *)calloc((size_t)gcap, sizeof(ivec));
+    ivec *gtex = (ivec *)calloc((size_t)gcap, sizeof(ivec)); /* elementsTexIDs */
     int *gmat = (int *)malloc((size_t)gcap * sizeof(int));
     gmat[0] = -1;
     int current_mat = -1;
@@ -261,9 +347,11 @@ orc_scene *orc_scene_load_obj(const char *path) {
                 if (ngroups == gcap) {
                     gcap *= 2;
                     groups = (ivec *)realloc(groups, (size_t)gcap * sizeof(ivec));
+                    gtex = (ivec *)realloc(gtex, (size_t)gcap * sizeof(ivec));
                     gmat = (int *)realloc(gmat, (size_t)gcap * sizeof(int));
                 }
                 memset(&groups[ngroups], 0, sizeof(ivec));
+                memset(&gtex[ngroups], 0, sizeof(ivec));
                 gmat[ngroups] = -1;
                 ++ngroups;
             }
@@ -281,14 +369,23 @@ orc_scene *orc_scene_load_obj(const char *path) {
             char *p = len >= 3 ? line + 3 : line + len;
             float x = strtof(p, &p), y = strtof(p, &p), z = strtof(p, &p);
             fvec_push3(&norm, x, y, z);
+        } else if (line[0] == 'v' && line[1] == 't') { /* objimporter.hpp:222-228 */
+            char *p = line + 2;
+            float u = strtof(p, &p), v = strtof(p, &p);
+            fvec_push3(&vt, u, v, 0.0f);
         } else if (line[0] == 'f' && line[1] == ' ') {
-            /* every whitespace-separated element contributes its vertex id; no triangulation */
+            /* every whitespace-separated element contributes its vertex id; no triangulation.  A non-empty
+             * second field is a texture-coordinate id (:249-256); the third (normal id) is never used. */
             char *p = line + 2;
             for (;;) {
                 while (*p == ' ' || *p == '\t' || *p == '\r') ++p;
                 if (!*p) break;
                 int id = (int)strtol(p, NULL, 10);
                 ivec_push(&groups[ngroups - 1], id - 1);
+                char *q = p;
+                while (*q && *q != ' ' && *q != '\t' && *q != '\r' && *q != '/') ++q;
+                if (*q == '/' && q[1] && q[1] != '/' && q[1] != ' ' && q[1] != '\t' && q[1] != '\r')
+                    ivec_push(&gtex[ngroups - 1], (int)strtol(q + 1, NULL, 10) - 1);
                 while (*p && *p != ' ' && *p != '\t' && *p != '\r') ++p;
             }
         }
@@ -304,18 +401,53 @@ orc_scene *orc_scene_load_obj(const char *path) {
     s->nf = nf;
     s->fvid = (int *)calloc((size_t)nf * 3 + 1, sizeof(int));
     s->fmat = (int *)calloc((size_t)nf + 1, sizeof(int));
-    int f = 0;
+    /* Texture coordinates, objimporter.hpp:51-79,325-337 and mesh.hpp:463-468.  Per group a per-VERTEX table
+     * (default (-1,-1)): the j-th texture id of the group goes to the vertex named by the j-th vertex id of
+     * the group, later entries overwrite earlier ones.  Faces of the id-th NON-EMPTY group then read table
+     * number id of ALL groups (the two numberings agree unless an empty group sits in front). */
+    const int nvt = (int)(vt.n / 3);
+    float **tables = NULL;
+    if (nvt > 0) {
+        s->ftex = (float *)calloc((size_t)nf * 6 + 1, sizeof(float));
+        tables = (float **)calloc((size_t)ngroups, sizeof(float *));
+        for (int g = 0; g < ngroups; ++g) {
+            tables[g] = (float *)malloc((size_t)(s->nv > 0 ? s->nv : 1) * 2 * sizeof(float));
+            for (int i = 0; i < 2 * s->nv; ++i) tables[g][i] = -1.0f;
+            for (size_t j = 0; j < gtex[g].n && j < groups[g].n; ++j) {
+                const int vid = groups[g].p[j], tid = gtex[g].p[j];
+                if (vid < 0 || vid >= s->nv || tid < 0 || tid >= nvt) continue; /* out of range in the reference: undefined */
+                tables[g][2 * vid] = vt.p[3 * tid], tables[g][2 * vid + 1] = vt.p[3 * tid + 1];
+            }
+        }
+    }
+    int f = 0, nonempty = 0;
     for (int g = 0; g < ngroups; ++g) {
+        if (groups[g].n == 0) continue; /* objimporter.hpp:315-322: only non-empty groups become index buffers */
         for (size_t i = 0; i + 2 < groups[g].n; i += 3, ++f) {
             s->fvid[3 * f] = groups[g].p[i];
             s->fvid[3 * f + 1] = groups[g].p[i + 1];
             s->fvid[3 * f + 2] = groups[g].p[i + 2];
             s->fmat[f] = gmat[g];
+            if (tables)
+                for (int k = 0; k < 3; ++k) {
+                    const int vid = s->fvid[3 * f + k];
+                    const float *row = tables[nonempty];
+                    s->ftex[6 * f + 2 * k] = vid >= 0 && vid < s->nv ? row[2 * vid] : -1.0f;
+                    s->ftex[6 * f + 2 * k + 1] = vid >= 0 && vid < s->nv ? row[2 * vid + 1] : -1.0f;
+                }
         }
-        free(groups[g].p);
+        ++nonempty;
     }
+    for (int g = 0; g < ngroups; ++g) {
+        free(groups[g].p);
+        free(gtex[g].p);
+        if (tables) free(tables[g]);
+    }
+    free(tables);
     free(groups);
+    free(gtex);
     free(gmat);
+    free(vt.p);
 
     /* normals: file normals paired with vertices by position when the counts agree, else recomputed
      * (objimporter.hpp:290-300; the normal indices of the f records are never used) */
@@ -329,8 +461,46 @@ orc_scene *orc_scene_load_obj(const char *path) {
 
     s->mats_plain = (orc_material *)calloc((size_t)(s->nmat > 0 ? s->nmat : 1), sizeof(orc_material));
     for (int i = 0; i < s->nmat; ++i) s->mats_plain[i] = s->mats[i].m;
+    load_material_textures(s);
     return s;
 }
+
+/* Textures for scenes given as arrays: texcoords = nf*6 or NULL; textures are appended one by one and tied
+ * to materials by index. */
+void orc_scene_set_texcoords(orc_scene *s, const float *texcoords) {
+    free(s->ftex);
+    s->ftex = NULL;
+    if (!texcoords) return;
+    s->ftex = (float *)malloc((size_t)s->nf * 6 * sizeof(float) + 4);
+    memcpy(s->ftex, texcoords, (size_t)s->nf * 6 * sizeof(float));
+}
+
+int32_t orc_scene_add_texture(orc_scene *s, int32_t width, int32_t height, const float *rgb) {
+    s->tex = (orc_tex *)realloc(s->tex, (size_t)(s->ntex + 1) * sizeof(orc_tex));
+    orc_tex *t = &s->tex[s->ntex];
+    memset(t, 0, sizeof *t);
+    t->w = width, t->h = height;
+    t->rgb = (float *)malloc((size_t)width * height * 3 * sizeof(float) + 4);
+    memcpy(t->rgb, rgb, (size_t)width * height * 3 * sizeof(float));
+    return s->ntex++;
+}
+
+void orc_scene_set_material_texture(orc_scene *s, int32_t material, int32_t texture) {
+    if (!s->mat_tex) {
+        s->mat_tex = (int *)malloc((size_t)(s->nmat > 0 ? s->nmat : 1) * sizeof(int));
+        for (int i = 0; i < s->nmat; ++i) s->mat_tex[i] = -1;
+    }
+    if (material >= 0 && material < s->nmat) s->mat_tex[material] = texture;
+}
+
+const float *orc_face_texcoords(const orc_scene *s) { return s->ftex; }
+int32_t orc_num_textures(const orc_scene *s) { return s->ntex; }
+const float *orc_texture_data(const orc_scene *s, int32_t i, int32_t *width, int32_t *height) {
+    if (i < 0 || i >= s->ntex) return NULL;
+    *width = s->tex[i].w, *height = s->tex[i].h;
+    return s->tex[i].rgb;
+}
+const int32_t *orc_material_textures(const orc_scene *s) { return s->mat_tex; }
 
 orc_scene *orc_scene_from_arrays(const float *vertices, const float *normals, int32_t nv, const int32_t *faces,
                                  const int32_t *face_material, int32_t nf, const orc_material *materials,
@@ -367,6 +537,9 @@ void orc_scene_free(orc_scene *s) {
     if (!s) return;
     free(s->raw_v), free(s->raw_n), free(s->fvid), free(s->fnormal), free(s->fmat);
     free(s->mats), free(s->mats_plain);
+    free(s->ftex), free(s->mat_tex);
+    for (int i = 0; i < s->ntex; ++i) free(s->tex[i].rgb);
+    free(s->tex);
     free(s->P_v), free(s->P_n), free(s->P_D);
     free(s->light_pos), free(s->light_col), free(s->samples), free(s->spheres);
     free_node(s->root);
@@ -802,7 +975,7 @@ static float light_intensity(tctx *c, v3 hit) {
     return f_min(li, 1.0f);
 }
 
-/* Flyscene::shadeOffFace, flyscene.cpp:461-579 (texture branch :516-542 not restated) */
+/* Flyscene::shadeOffFace, flyscene.cpp:461-579 */
 static v3 shade_off_face(tctx *c, int face, v3 origin, v3 hit, v3 LI) {
     const orc_scene *s = c->s;
     if (face == -1) return v3_make(0.7f, 0.9f, 0.0f);
@@ -822,13 +995,35 @@ static v3 shade_off_face(tctx *c, int face, v3 origin, v3 hit, v3 LI) {
     const v3 ka = v3_make(m->ka[0], m->ka[1], m->ka[2]);
     const v3 kd = v3_make(m->kd[0], m->kd[1], m->kd[2]);
     const v3 ks = v3_make(m->ks[0], m->ks[1], m->ks[2]);
+    /* :476-481: the face carries three texture coordinates (any `vt` in the file gives every face three) and
+     * the material names a texture */
+    const orc_tex *tex = s->ftex && s->mat_tex && s->mat_tex[mat] >= 0 ? &s->tex[s->mat_tex[mat]] : NULL;
+    v3 texel = v3_make(0, 0, 0);
+    if (tex) {
+        /* :519-539.  The weights are the absolute sub-triangle areas, NOT divided by the face area.  uacc and
+         * vacc are floors of fractional parts, i.e. always 0, so the "interpolation" is 1*cij + 0*... = the
+         * texel at (projU, projV).  The reference indexes the vector unchecked; an index outside the image
+         * (undefined there) is clamped to it here. */
+        const float *tc = s->ftex + 6 * face;
+        const float u = (a12 * tc[0] + a02 * tc[2]) + a01 * tc[4];
+        const float v = (a12 * tc[1] + a02 * tc[3]) + a01 * tc[5];
+        const float fu = floorf(u * (float)tex->w), fv = floorf(v * (float)tex->h);
+        const long last = (long)tex->w * tex->h - 1;
+        double idx = (double)fv * (double)tex->w + (double)fu;
+        long at = !(idx >= 0) ? 0 : idx > (double)last ? last : (long)idx;
+        if (last < 0) {
+            tex = NULL; /* unreadable file: the reference reads an empty vector; here the material colour is used */
+        } else {
+            texel = v3_make(tex->rgb[3 * at], tex->rgb[3 * at + 1], tex->rgb[3 * at + 2]);
+        }
+    }
     v3 color = v3_make(0, 0, 0);
     for (int l = 0; l < s->nl; ++l) {
         const v3 lp = v3_make(s->light_pos[3 * l], s->light_pos[3 * l + 1], s->light_pos[3 * l + 2]);
         const v3 L = v3_normalized(v3_sub(lp, hit));
         const v3 ambient = v3_mul(LI, ka);
         const float cos1 = fmaxf(0, v3_dot(L, N));
-        const v3 diffuse = v3_scale(cos1, v3_mul(LI, kd));
+        const v3 diffuse = v3_scale(cos1, v3_mul(LI, tex ? texel : kd)); /* :514 / :541 */
         const v3 E = v3_normalized(v3_sub(origin, hit));
         const v3 R = v3_normalized(v3_add(v3_neg(L), v3_scale(2.f * v3_dot(L, N), N)));
         const float cos2 = (float)fmax(0, (double)v3_dot(R, E));

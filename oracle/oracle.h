@@ -81,6 +81,17 @@ orc_scene *orc_scene_from_arrays(const float *vertices, const float *normals, in
                                  const orc_material *materials, int32_t nmat);
 void orc_scene_free(orc_scene *s);
 
+/* Texture path (shadeOffFace :516-542).  orc_scene_load_obj reads `vt`, `map_kd` and the PPM files itself;
+ * these serve scenes built from arrays.  texcoords = nf*6 (u,v per corner, Face::texcoord) or NULL;
+ * rgb = width*height*3 in the row order of texturedatas (file rows flipped, ppmIO.hpp:68-77). */
+void orc_scene_set_texcoords(orc_scene *s, const float *texcoords);
+int32_t orc_scene_add_texture(orc_scene *s, int32_t width, int32_t height, const float *rgb);
+void orc_scene_set_material_texture(orc_scene *s, int32_t material, int32_t texture);
+const float *orc_face_texcoords(const orc_scene *s);          /* nf*6 or NULL                      */
+int32_t orc_num_textures(const orc_scene *s);
+const float *orc_texture_data(const orc_scene *s, int32_t i, int32_t *width, int32_t *height);
+const int32_t *orc_material_textures(const orc_scene *s);     /* nmat or NULL                      */
+
 /* S3+S4: mesh.normalizeModelMatrix() + Flyscene::precomputeData, flyscene.cpp:165-219. */
 void orc_scene_precompute(orc_scene *s, int32_t normalize_model);
 /* lights: pos_color = L x 6 floats.  S5: Flyscene::precomputeLights, flyscene.cpp:221-250. */

@@ -87,6 +87,18 @@ def load(fast=False):
     lib.orc_scene_set_lights.argtypes = [P, fp, C.c_int32, C.c_int32, C.c_int32, C.c_float]
     lib.orc_scene_set_spheres.argtypes = [P, fp, C.c_int32]
     lib.orc_scene_build_bvh.argtypes = [P]
+    lib.orc_scene_set_texcoords.argtypes = [P, fp]
+    lib.orc_scene_add_texture.restype = C.c_int32
+    lib.orc_scene_add_texture.argtypes = [P, C.c_int32, C.c_int32, fp]
+    lib.orc_scene_set_material_texture.argtypes = [P, C.c_int32, C.c_int32]
+    lib.orc_face_texcoords.restype = fp
+    lib.orc_face_texcoords.argtypes = [P]
+    lib.orc_num_textures.restype = C.c_int32
+    lib.orc_num_textures.argtypes = [P]
+    lib.orc_texture_data.restype = fp
+    lib.orc_texture_data.argtypes = [P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.orc_material_textures.restype = ip
+    lib.orc_material_textures.argtypes = [P]
     for fn in ("orc_num_vertices", "orc_num_faces", "orc_num_materials", "orc_num_lights", "orc_samples_per_light",
                "orc_bvh_node_count", "orc_bvh_leaf_count", "orc_bvh_depth"):
         getattr(lib, fn).restype = C.c_int32
@@ -138,7 +150,7 @@ class OracleScene:
     (flyscene.cpp:18-134)."""
 
     def __init__(self, obj_path=None, arrays=None, lights=DEFAULT_LIGHTS, hard_shadow=True, soft_points=12,
-                 soft_radius=0.3, spheres=(), normalize_model=True, fast=False):
+                 soft_radius=0.3, spheres=(), normalize_model=True, fast=False, textures=None):
         self.lib = load(fast)
         if obj_path is not None:
             self.h = self.lib.orc_scene_load_obj(os.fsencode(obj_path))
@@ -160,6 +172,15 @@ class OracleScene:
                 marr[i].ks[:] = m["ks"]
                 marr[i].shininess = m["shininess"]
             self.h = self.lib.orc_scene_from_arrays(_fptr(v), nptr, len(v), _iptr(f), _iptr(fm), len(f), marr, len(mats))
+            if textures is not None:
+                tc = np.ascontiguousarray(textures["face_texcoords"], np.float32).reshape(len(f), 6)
+                self.lib.orc_scene_set_texcoords(self.h, _fptr(tc))
+                ids = []
+                for im in textures["images"]:
+                    im = np.ascontiguousarray(im, np.float32)
+                    ids.append(self.lib.orc_scene_add_texture(self.h, im.shape[1], im.shape[0], _fptr(im)))
+                for m, t in enumerate(np.asarray(textures["material_textures"], np.int32).reshape(-1)):
+                    self.lib.orc_scene_set_material_texture(self.h, m, ids[t] if t >= 0 else -1)
         self.lib.orc_scene_precompute(self.h, 1 if normalize_model else 0)
         self.set_lights(lights, hard_shadow, soft_points, soft_radius)
         sp = np.ascontiguousarray(np.array(spheres, np.float32).reshape(-1, 4))
@@ -209,6 +230,20 @@ class OracleScene:
             "light_samples": _arr(L.orc_light_samples(self.h), (nl, spl, 3), np.float32),
             "model_matrix": _arr(L.orc_model_matrix(self.h), (3, 4), np.float32),
         }
+
+    def texture_arrays(self):
+        """Face::texcoord, material -> texture, texturedatas (flyscene.cpp:52-71,476-481,502)."""
+        L = self.lib
+        nf, nm = self.nf, L.orc_num_materials(self.h)
+        tc = L.orc_face_texcoords(self.h)
+        mt = L.orc_material_textures(self.h)
+        out = {"face_texcoords": _arr(tc, (nf, 3, 2), np.float32) if tc else np.zeros((0, 3, 2), np.float32),
+               "material_textures": _arr(mt, (nm,), np.int32) if mt else np.full(nm, -1, np.int32), "images": []}
+        for k in range(L.orc_num_textures(self.h)):
+            w, h = C.c_int32(), C.c_int32()
+            p = L.orc_texture_data(self.h, k, C.byref(w), C.byref(h))
+            out["images"].append(_arr(p, (h.value, w.value, 3), np.float32))
+        return out
 
     def bvh_stats(self):
         L = self.lib

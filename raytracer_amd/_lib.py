@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(_HERE, "lib", "librtamd.s
 
 OK, ERR_INVALID, ERR_HIP, ERR_LIMIT, ERR_NO_DEVICE = 0, 1, 2, 3, 4
 FACE_SPHERE, FACE_MISS = -1, -2
-FLAG_COUNT_WORK, FLAG_TIME_KERNELS = 1, 2
+FLAG_COUNT_WORK, FLAG_TIME_KERNELS, FLAG_SINGLE_STREAM = 1, 2, 4
 
 
 class Material(C.Structure):
@@ -23,6 +23,10 @@ class Sphere(C.Structure):
 _fp, _ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
 
 
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgb", _fp)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [
         ("vertices", _fp), ("normals", _fp), ("num_vertices", C.c_int32),
@@ -32,6 +36,7 @@ class SceneDesc(C.Structure):
         ("light_positions", _fp), ("light_colors", _fp), ("num_lights", C.c_int32),
         ("light_samples", _fp), ("samples_per_light", C.c_int32),
         ("spheres", C.POINTER(Sphere)), ("num_spheres", C.c_int32),
+        ("face_texcoords", _fp), ("material_textures", _ip), ("textures", C.POINTER(Texture)), ("num_textures", C.c_int32),
     ]
 
 
@@ -107,6 +112,7 @@ SYMBOLS = {
     "rtfly_destroy": (C.c_int, [_P]),
     "rtfly_set_model": (C.c_int, [_P, C.c_char_p]),
     "rtfly_set_model_arrays": (C.c_int, [_P, _fp, _fp, C.c_int32, _ip, _ip, C.c_int32, C.POINTER(Material), C.c_int32]),
+    "rtfly_set_texture_arrays": (C.c_int, [_P, _fp, _ip, C.POINTER(Texture), C.c_int32]),
     "rtfly_clear_lights": (C.c_int, [_P]),
     "rtfly_add_light_at": (C.c_int, [_P, _fp, _fp]),
     "rtfly_set_shadow_sampling": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_float]),

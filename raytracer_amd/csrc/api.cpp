@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <map>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -61,7 +63,7 @@ struct rtamd_scene {
     int device = -1;
     int num_cus = 256;
     void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_materials = nullptr;
-    void *d_light_pos = nullptr, *d_samples = nullptr, *d_spheres = nullptr;
+    void *d_light_pos = nullptr, *d_samples = nullptr, *d_spheres = nullptr, *d_texels = nullptr, *d_tex_info = nullptr;
     DeviceScene ds{};
     Workspace ws{};
     void *ws_block = nullptr;
@@ -81,8 +83,7 @@ struct rtamd_scene {
     // HIP-event pairs of every launch (kind 0..4) and frame (kind 5) since the last stats call
     std::vector<TimedLaunch> events;
     size_t events_used = 0;
-    // Extra streams of a frame with reflections (see rtamd_render_device); `sync` holds the events that order them.
-    hipStream_t geometry_stream = nullptr, deep_shadow_stream = nullptr;
+    // events that order the streams of a frame with reflections (see rtamd_render_device)
     std::vector<hipEvent_t> sync;
 };
 
@@ -137,6 +138,32 @@ int check_params(const rtamd_scene *s, const rtamd_camera *cam, const rtamd_rend
     if (p->row_tile < 1 || p->num_parts < 1 || p->part < 0 || p->part >= p->num_parts)
         return fail(RTAMD_ERR_INVALID, "row partition (tile %d, parts %d, part %d)", p->row_tile, p->num_parts, p->part);
     if (!(cam->viewport[2] > 0) || !(cam->viewport[3] > 0)) return fail(RTAMD_ERR_INVALID, "empty viewport");
+    return RTAMD_OK;
+}
+
+// Side streams of frames with reflections: ONE pair per device for the whole process, shared by every scene.
+// A process has few hardware queues (four by default); once the streams in use outnumber them, streams share
+// a queue, and a wait queued ahead of the work it waits for, in the same hardware queue, never ends -- seen
+// with two reflective scenes alive, each with streams of its own.  The side chains are the critical path of
+// such a frame (few rays, long dependent chains), so their waves get dispatch priority over the large
+// depth-0 shadow launch they overlap.
+struct SideStreams {
+    hipStream_t geometry = nullptr, deep_shadow = nullptr;
+};
+int side_streams(int device, SideStreams **out) {
+    static std::mutex lock;
+    static std::map<int, SideStreams> per_device;
+    std::lock_guard<std::mutex> guard(lock);
+    SideStreams &ss = per_device[device];
+    if (!ss.geometry) {
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        static const bool flat = getenv("RTAMD_FLAT_PRIORITY") != nullptr; // experiment hook
+        const int prio = flat ? least : greatest;
+        HIP_TRY(hipStreamCreateWithPriority(&ss.geometry, hipStreamNonBlocking, prio));
+        HIP_TRY(hipStreamCreateWithPriority(&ss.deep_shadow, hipStreamNonBlocking, prio));
+    }
+    *out = &ss;
     return RTAMD_OK;
 }
 
@@ -217,6 +244,22 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
         if (m < -1 || m >= d->num_materials) return fail(RTAMD_ERR_INVALID, "face %d references material %d of %d", f, m, d->num_materials);
     }
 
+    if (d->num_textures < 0) return fail(RTAMD_ERR_INVALID, "negative texture count");
+    if (d->num_textures > 0) {
+        if (!d->textures || !d->material_textures || !d->face_texcoords)
+            return fail(RTAMD_ERR_INVALID, "textures given without texture coordinates or the material table");
+        int64_t texel_total = 0;
+        for (int32_t i = 0; i < d->num_textures; ++i) {
+            const rtamd_texture &t = d->textures[i];
+            if (t.width <= 0 || t.height <= 0 || !t.rgb) return fail(RTAMD_ERR_INVALID, "texture %d is empty", i);
+            texel_total += (int64_t)t.width * t.height;
+        }
+        if (texel_total >= (1ll << 29)) return fail(RTAMD_ERR_LIMIT, "%lld texels exceed the 2^29 limit", (long long)texel_total);
+        for (int32_t i = 0; i < d->num_materials; ++i)
+            if (d->material_textures[i] < -1 || d->material_textures[i] >= d->num_textures)
+                return fail(RTAMD_ERR_INVALID, "material %d references texture %d of %d", i, d->material_textures[i], d->num_textures);
+    }
+
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RTAMD_ERR_NO_DEVICE, "no HIP device available");
     int dev = 0;
@@ -244,6 +287,7 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
         delete s;
         return fail(RTAMD_ERR_LIMIT, "BVH needs %d traversal stack entries, the kernels hold %d", bvh.stack_need, kStackEntries);
     }
+    const bool textured = d->num_textures > 0 && d->face_texcoords && d->material_textures && d->textures;
     std::vector<ShadeRecord> shade((size_t)d->num_faces);
     for (int32_t f = 0; f < d->num_faces; ++f) {
         ShadeRecord &r = shade[f];
@@ -257,19 +301,32 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
         std::memcpy(r.n2, d->normals + 3 * (size_t)id[2], 12);
         std::memcpy(r.fn, d->face_normals + 3 * (size_t)f, 12);
         r.material = d->face_material_ids[f];
+        if (textured) std::memcpy(r.tc, d->face_texcoords + 6 * (size_t)f, 24);
     }
     const double t1 = now_ms();
 
     // ---- upload
     uint64_t bytes = 0;
     int rc = RTAMD_OK;
-    std::vector<float> mats((size_t)d->num_materials * 10);
+    std::vector<float> mats((size_t)d->num_materials * kMaterialFloats);
     for (int32_t i = 0; i < d->num_materials; ++i) {
-        std::memcpy(&mats[10 * (size_t)i], d->materials[i].ka, 12);
-        std::memcpy(&mats[10 * (size_t)i + 3], d->materials[i].kd, 12);
-        std::memcpy(&mats[10 * (size_t)i + 6], d->materials[i].ks, 12);
-        mats[10 * (size_t)i + 9] = d->materials[i].shininess;
+        float *m = &mats[(size_t)kMaterialFloats * (size_t)i];
+        std::memcpy(m, d->materials[i].ka, 12);
+        std::memcpy(m + 3, d->materials[i].kd, 12);
+        std::memcpy(m + 6, d->materials[i].ks, 12);
+        m[9] = d->materials[i].shininess;
+        const int32_t tex = textured ? d->material_textures[i] : -1;
+        std::memcpy(m + 10, &tex, 4);
     }
+    std::vector<float> texels;
+    std::vector<int32_t> tex_info;
+    if (textured)
+        for (int32_t i = 0; i < d->num_textures; ++i) {
+            const rtamd_texture &t = d->textures[i];
+            const int32_t first = (int32_t)(texels.size() / 3);
+            tex_info.insert(tex_info.end(), {first, t.width, t.height, 0});
+            texels.insert(texels.end(), t.rgb, t.rgb + (size_t)t.width * t.height * 3);
+        }
     std::vector<float> lpos(d->light_positions, d->light_positions + 3 * (size_t)d->num_lights);
     std::vector<float> samples(d->light_samples, d->light_samples + 3 * (size_t)d->num_lights * d->samples_per_light);
     std::vector<rtamd_sphere> spheres(d->spheres, d->spheres + d->num_spheres);
@@ -280,6 +337,8 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     if (rc == RTAMD_OK) rc = upload(&s->d_light_pos, lpos, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_samples, samples, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_spheres, spheres, &bytes);
+    if (rc == RTAMD_OK) rc = upload(&s->d_texels, texels, &bytes);
+    if (rc == RTAMD_OK) rc = upload(&s->d_tex_info, tex_info, &bytes);
     if (rc != RTAMD_OK) {
         rtamd_scene_destroy(s);
         return rc;
@@ -293,6 +352,9 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     s->ds.light_pos = (const float *)s->d_light_pos;
     s->ds.samples = (const float *)s->d_samples;
     s->ds.spheres = (const float4 *)s->d_spheres;
+    s->ds.texels = (const float *)s->d_texels;
+    s->ds.tex_info = (const int32_t *)s->d_tex_info;
+    s->ds.num_textures = textured ? d->num_textures : 0;
     s->ds.num_lights = d->num_lights;
     s->ds.spl = d->samples_per_light;
     s->ds.num_spheres = d->num_spheres;
@@ -328,7 +390,8 @@ int rtamd_reference_face_rank(const rtamd_scene_desc *d, int32_t *rank_out) {
 
 int rtamd_scene_destroy(rtamd_scene *s) {
     if (!s) return RTAMD_OK;
-    void *bufs[] = {s->d_nodes, s->d_tris, s->d_shade, s->d_materials, s->d_light_pos, s->d_samples, s->d_spheres, s->ws_block, s->d_rgb, s->d_face};
+    void *bufs[] = {s->d_nodes, s->d_tris,  s->d_shade,  s->d_materials, s->d_light_pos, s->d_samples,
+                    s->d_spheres, s->d_texels, s->d_tex_info, s->ws_block, s->d_rgb, s->d_face};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (TimedLaunch &t : s->events) {
@@ -336,8 +399,6 @@ int rtamd_scene_destroy(rtamd_scene *s) {
         (void)hipEventDestroy(t.stop);
     }
     for (hipEvent_t e : s->sync) (void)hipEventDestroy(e);
-    if (s->geometry_stream) (void)hipStreamDestroy(s->geometry_stream);
-    if (s->deep_shadow_stream) (void)hipStreamDestroy(s->deep_shadow_stream);
     delete s;
     return RTAMD_OK;
 }
@@ -427,19 +488,13 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     // all shading runs in order.  Buffers rotate (hit lists and shadow results by d & 1, queues by d % 3):
     // compact(d + 2) is the first kernel to overwrite what shade(d) reads, and waits for it.
     static const bool serial = getenv("RTAMD_SERIAL") != nullptr; // experiment hook: everything on the caller's stream
-    const bool two_streams = depths > 1 && !serial;
+    const bool two_streams = depths > 1 && !serial && (p->flags & RTAMD_FLAG_SINGLE_STREAM) == 0;
     hipStream_t geo = stream, deep = stream;
     if (two_streams) {
-        // The side chains are the critical path of the frame (few rays, long dependent chains): their waves get
-        // dispatch priority over the large depth-0 shadow launch they overlap.
-        int least = 0, greatest = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        static const bool flat = getenv("RTAMD_FLAT_PRIORITY") != nullptr; // experiment hook
-        const int prio = flat ? least : greatest;
-        if (!s->geometry_stream) HIP_TRY(hipStreamCreateWithPriority(&s->geometry_stream, hipStreamNonBlocking, prio));
-        if (!s->deep_shadow_stream) HIP_TRY(hipStreamCreateWithPriority(&s->deep_shadow_stream, hipStreamNonBlocking, prio));
-        geo = s->geometry_stream;
-        deep = s->deep_shadow_stream;
+        SideStreams *side = nullptr;
+        if ((rc = side_streams(s->device, &side)) != RTAMD_OK) return rc;
+        geo = side->geometry;
+        deep = side->deep_shadow;
         while (s->sync.size() < (size_t)(3 * depths + 1)) {
             hipEvent_t e;
             HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -49,14 +49,16 @@ struct alignas(64) TriRecord {
     int32_t pad;
 };
 
-// 96 B, indexed by the caller's face index.  What shadeOffFace reads (src/flyscene.cpp:469-500).
-struct alignas(32) ShadeRecord {
+// 128 B, indexed by the caller's face index.  What shadeOffFace reads (src/flyscene.cpp:469-502).
+struct alignas(128) ShadeRecord {
     float v0[3], v1[3], v2[3];
     float n0[3], n1[3], n2[3];
     float fn[3];
     int32_t material;
-    int32_t pad[2];
+    float tc[6]; // Face::texcoord: (u,v) of the three corners
+    int32_t pad[4];
 };
+static_assert(sizeof(ShadeRecord) == 128, "kernels index ShadeRecord as 8 float4");
 
 constexpr int kMaxLeafFaces = 15;
 constexpr int kMaxTreeDepth = 32; // of the binary tree

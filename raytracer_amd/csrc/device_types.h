@@ -6,18 +6,23 @@ namespace rtamd {
 
 constexpr int kStackEntries = 64;   // per-lane traversal stack (LDS + private memory); scene creation checks the tree against it
 constexpr int kMaxShadowRays = 512; // lights * samples_per_light per hit
+constexpr int kShadeRecordQuads = 8; // float4 per ShadeRecord (bvh.hpp)
+constexpr int kMaterialFloats = 12;  // ka, kd, ks, shininess, texture index (int bits), pad
 constexpr int kMaxStages = 64;      // (ssaa passes) * (max_reflections + 1) counter slots per frame
 
 // Read-only scene in HBM.
 struct DeviceScene {
     const float4 *nodes;      // 8 x float4 per Bvh4Node
     const float4 *tris;       // 4 x float4 per TriRecord
-    const float4 *shade;      // 6 x float4 per ShadeRecord, indexed by face
-    const float *materials;   // 10 floats per material: ka, kd, ks, shininess
+    const float4 *shade;      // 8 x float4 per ShadeRecord, indexed by face
+    const float *materials;   // 12 floats per material: ka, kd, ks, shininess, texture index (int bits), pad
+    const float *texels;      // all textures back to back, 3 floats per texel
+    const int32_t *tex_info;  // per texture: first texel, width, height, 0
     const float *light_pos;   // 3 per light
     const float *samples;     // 3 per (light, sample)
     const float4 *spheres;    // center, radius
     int32_t num_lights, spl, num_spheres, num_materials;
+    int32_t num_textures; // 0 also when the mesh has no texture coordinates
 };
 
 // Per-launch constants (camera + the reference's macros).

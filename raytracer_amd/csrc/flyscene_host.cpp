@@ -104,14 +104,73 @@ bool load_mtl(const std::string &path, std::vector<NamedMaterial> &materials) {
                 m.kd[0] = num(1), m.kd[1] = num(2), m.kd[2] = num(3);
             } else if (key == "Ks") {
                 m.ks[0] = num(1), m.ks[1] = num(2), m.ks[2] = num(3);
+            } else if (key == "map_kd") { // lower case only, :122-125: directory of the MTL file + the name as written
+                materials.back().diffuse_texture = directory_of(path) + (tok.size() > 1 ? tok[1] : std::string());
             }
-            // Ni, d, illum and map_kd are parsed by the reference but not read by the traced path
+            // Ni, d and illum are parsed by the reference but not read by the traced path
         }
     }
     if (materials.empty()) { // :130-134
         NamedMaterial nm;
         nm.m = default_material();
         materials.push_back(nm);
+    }
+    return true;
+}
+
+// ImageImporter::loadPPMImageData, utils/ppmIO.hpp:36-86: header word, width, height, maximum, then every
+// number divided by the maximum; the rows are handed back bottom row first (:68-77).  The reference goes on
+// with empty data when the file is missing or short and then indexes it; here that is an error.
+bool load_ppm_texture(const std::string &path, HostTexture &tex, std::string &error) {
+    std::string fn = path;
+    erase_crlf(fn); // :40-41
+    tex = HostTexture();
+    tex.file = fn;
+    std::ifstream in(fn.c_str());
+    if (!in) {
+        error = "Cannot open " + fn;
+        return false;
+    }
+    std::string header;
+    int w = 0, h = 0;
+    float max_value = 0.0f;
+    in >> header;
+    in >> w >> h;
+    in >> max_value;
+    if (!in || w <= 0 || h <= 0) {
+        error = "not an ASCII PPM image: " + fn;
+        return false;
+    }
+    std::vector<float> data;
+    data.reserve((size_t)w * h * 3);
+    float value;
+    while (data.size() < (size_t)w * h * 3 && in >> value) data.push_back(value / max_value); // :57-60
+    if (data.size() < (size_t)w * h * 3) {
+        error = "texture " + fn + " holds fewer than width*height*3 values";
+        return false;
+    }
+    tex.width = w, tex.height = h;
+    tex.rgb.resize(data.size());
+    for (int j = h - 1, r = 0; j >= 0; --j, ++r)
+        std::memcpy(&tex.rgb[(size_t)r * w * 3], &data[(size_t)j * w * 3], (size_t)w * 3 * sizeof(float));
+    return true;
+}
+
+// Flyscene::initialize, src/flyscene.cpp:52-71: one entry per distinct file name (std::map::insert keeps the first).
+bool load_material_textures(HostMesh &mesh, std::string &error) {
+    mesh.textures.clear();
+    mesh.material_texture.assign(mesh.materials.size(), -1);
+    for (size_t i = 0; i < mesh.materials.size(); ++i) {
+        std::string fn = mesh.materials[i].diffuse_texture;
+        if (fn.empty()) continue;
+        erase_crlf(fn);
+        for (size_t k = 0; k < mesh.textures.size(); ++k)
+            if (mesh.textures[k].file == fn) mesh.material_texture[i] = (int32_t)k;
+        if (mesh.material_texture[i] >= 0) continue;
+        HostTexture t;
+        if (!load_ppm_texture(fn, t, error)) return false;
+        mesh.material_texture[i] = (int32_t)mesh.textures.size();
+        mesh.textures.push_back(std::move(t));
     }
     return true;
 }
@@ -144,8 +203,12 @@ void finish_mesh(HostMesh &m, bool have_normals) {
 //    file order and emitted group by group);
 //  * every element of an `f` record contributes its vertex index -- no triangulation; faces are the
 //    consecutive index triples of each group;
-//  * the normal and texture indices of `f` records are ignored: `vn` k belongs to `v` k when the
-//    counts agree, otherwise vertex normals are recomputed from the faces.
+//  * the normal indices of `f` records are ignored: `vn` k belongs to `v` k when the counts agree,
+//    otherwise vertex normals are recomputed from the faces;
+//  * texture coordinates (objimporter.hpp:51-79,222-228,249-256,325-337; mesh.hpp:463-468) are kept per
+//    VERTEX and per group: the j-th texture index of a group is written to the vertex named by the j-th
+//    vertex index of that group (default (-1,-1), later records overwrite earlier ones), and the faces of
+//    the k-th non-empty group read table k of all groups.
 bool load_obj(const std::string &path, HostMesh &mesh, std::string &error) {
     std::ifstream in(path.c_str());
     if (!in) {
@@ -155,6 +218,8 @@ bool load_obj(const std::string &path, HostMesh &mesh, std::string &error) {
     mesh = HostMesh();
     const std::string dir = directory_of(path);
     std::vector<float> file_normals;
+    std::vector<float> file_texcoords;               // 2 per `vt`
+    std::vector<std::vector<int32_t>> group_tex(1);  // elementsTexIDs
     std::vector<std::vector<int32_t>> groups(1);
     std::vector<int32_t> group_material(1, -1);
     int32_t current_material = -1;
@@ -167,6 +232,7 @@ bool load_obj(const std::string &path, HostMesh &mesh, std::string &error) {
         } else if (line.compare(0, 6, "usemtl") == 0 && line.size() >= 7) {
             if (!groups.back().empty()) {
                 groups.emplace_back();
+                group_tex.emplace_back();
                 group_material.push_back(-1);
             }
             std::string name = line.substr(7);
@@ -188,14 +254,44 @@ bool load_obj(const std::string &path, HostMesh &mesh, std::string &error) {
                 file_normals.push_back(std::strtof(p, &e));
                 p = e;
             }
+        } else if (line.compare(0, 2, "vt") == 0) {
+            const char *p = line.c_str() + 2;
+            char *e;
+            for (int k = 0; k < 2; ++k) {
+                file_texcoords.push_back(std::strtof(p, &e));
+                p = e;
+            }
         } else if (line.compare(0, 2, "f ") == 0) {
             std::istringstream els(line.substr(2));
             std::string el;
-            while (els >> el) groups.back().push_back((int32_t)std::strtol(el.c_str(), nullptr, 10) - 1);
+            while (els >> el) {
+                groups.back().push_back((int32_t)std::strtol(el.c_str(), nullptr, 10) - 1);
+                const size_t slash = el.find('/');
+                if (slash != std::string::npos && slash + 1 < el.size() && el[slash + 1] != '/')
+                    group_tex.back().push_back((int32_t)std::strtol(el.c_str() + slash + 1, nullptr, 10) - 1);
+            }
         }
     }
     const int32_t nv = mesh.num_vertices();
-    for (size_t g = 0; g < groups.size(); ++g)
+    const int32_t nvt = (int32_t)(file_texcoords.size() / 2);
+    std::vector<std::vector<float>> tables; // createTexCoordsArrays: one per-vertex table per group
+    if (nvt > 0) {
+        tables.assign(groups.size(), std::vector<float>(2 * (size_t)nv, -1.0f));
+        for (size_t g = 0; g < groups.size(); ++g)
+            for (size_t j = 0; j < group_tex[g].size() && j < groups[g].size(); ++j) {
+                const int32_t vid = groups[g][j], tid = group_tex[g][j];
+                if (vid < 0 || vid >= nv) continue; // reported below, with the faces
+                if (tid < 0 || tid >= nvt) {
+                    error = "face references texture coordinate " + std::to_string(tid + 1) + " of " + std::to_string(nvt) + " in " + path;
+                    return false;
+                }
+                tables[g][2 * (size_t)vid] = file_texcoords[2 * (size_t)tid];
+                tables[g][2 * (size_t)vid + 1] = file_texcoords[2 * (size_t)tid + 1];
+            }
+    }
+    size_t nonempty = 0;
+    for (size_t g = 0; g < groups.size(); ++g) {
+        if (groups[g].empty()) continue; // only non-empty groups become index buffers, objimporter.hpp:315-322
         for (size_t i = 0; i + 2 < groups[g].size(); i += 3) {
             for (int k = 0; k < 3; ++k) {
                 const int32_t id = groups[g][i + k];
@@ -204,13 +300,19 @@ bool load_obj(const std::string &path, HostMesh &mesh, std::string &error) {
                     return false;
                 }
                 mesh.face_vertex.push_back(id);
+                if (nvt > 0) {
+                    mesh.face_texcoord.push_back(tables[nonempty][2 * (size_t)id]);
+                    mesh.face_texcoord.push_back(tables[nonempty][2 * (size_t)id + 1]);
+                }
             }
             mesh.face_material.push_back(group_material[g]);
         }
+        ++nonempty;
+    }
     const bool paired = (int32_t)(file_normals.size() / 3) == nv && nv > 0;
     if (paired) mesh.normals = file_normals;
     finish_mesh(mesh, paired);
-    return true;
+    return load_material_textures(mesh, error);
 }
 
 // utils/ppmIO.hpp:188-209: ASCII P3, each channel min(255, (int)(255 * c)), one text line per row.
@@ -461,6 +563,14 @@ int Flyscene::upload() {
     d.samples_per_light = (hard_shadow ? 1 : 0) + soft_points;
     d.spheres = spheres.data();
     d.num_spheres = (int32_t)spheres.size();
+    std::vector<rtamd_texture> tex;
+    for (const HostTexture &t : mesh.textures) tex.push_back(rtamd_texture{t.width, t.height, t.rgb.data()});
+    if (!mesh.face_texcoord.empty() && !tex.empty() && mesh.material_texture.size() == plain_materials.size()) {
+        d.face_texcoords = mesh.face_texcoord.data();
+        d.material_textures = mesh.material_texture.data();
+        d.textures = tex.data();
+        d.num_textures = (int32_t)tex.size();
+    }
     return rtamd_scene_create(&d, &build, &scene_);
 }
 
@@ -554,9 +664,32 @@ int rtfly_set_model_arrays(rtfly *f, const float *v, const float *n, int32_t nv,
     m.face_vertex.assign(faces, faces + 3 * (size_t)nf);
     m.face_material.assign((size_t)nf, -1);
     if (fm) m.face_material.assign(fm, fm + nf);
-    for (int32_t i = 0; i < nm; ++i) m.materials.push_back(rtamd::NamedMaterial{std::string(), mats[i]});
+    for (int32_t i = 0; i < nm; ++i) m.materials.push_back(rtamd::NamedMaterial{std::string(), mats[i], std::string()});
     rtamd::finish_mesh(m, n != nullptr);
     f->fly.mesh_from_arrays = true;
+    return RTAMD_OK;
+}
+int rtfly_set_texture_arrays(rtfly *f, const float *face_texcoords, const int32_t *material_textures, const rtamd_texture *textures,
+                             int32_t num_textures) {
+    if (!f || num_textures < 0 || (num_textures > 0 && (!textures || !material_textures || !face_texcoords))) return RTAMD_ERR_INVALID;
+    rtamd::HostMesh &m = f->fly.mesh;
+    m.face_texcoord.clear();
+    m.textures.clear();
+    m.material_texture.assign(m.materials.size(), -1);
+    if (num_textures == 0) return RTAMD_OK;
+    m.face_texcoord.assign(face_texcoords, face_texcoords + 6 * (size_t)m.num_faces());
+    for (int32_t i = 0; i < num_textures; ++i) {
+        if (textures[i].width <= 0 || textures[i].height <= 0 || !textures[i].rgb) return RTAMD_ERR_INVALID;
+        rtamd::HostTexture t;
+        t.width = textures[i].width, t.height = textures[i].height;
+        t.rgb.assign(textures[i].rgb, textures[i].rgb + (size_t)t.width * t.height * 3);
+        m.textures.push_back(std::move(t));
+    }
+    for (size_t i = 0; i < m.materials.size(); ++i) {
+        const int32_t t = material_textures[i];
+        if (t < -1 || t >= num_textures) return RTAMD_ERR_INVALID;
+        m.material_texture[i] = t;
+    }
     return RTAMD_OK;
 }
 int rtfly_clear_lights(rtfly *f) {
@@ -656,6 +789,18 @@ int rtfly_get_array(rtfly *f, const char *name, const void **data, int64_t *coun
     if (n == "model_matrix") return set(s.model_matrix, 12);
     if (n == "face_vertex_ids") return set(s.mesh.face_vertex.data(), s.mesh.face_vertex.size());
     if (n == "face_material_ids") return set(s.mesh.face_material.data(), s.mesh.face_material.size());
+    if (n == "face_texcoords") return set(s.mesh.face_texcoord.data(), s.mesh.face_texcoord.size());
+    if (n == "material_textures") return set(s.mesh.material_texture.data(), s.mesh.material_texture.size());
+    if (n.compare(0, 8, "texture:") == 0) { // "texture:<k>" -> texels; "texture_size:<k>" below -> (width, height)
+        const size_t k = (size_t)std::strtoul(n.c_str() + 8, nullptr, 10);
+        if (k >= s.mesh.textures.size()) return RTAMD_ERR_INVALID;
+        return set(s.mesh.textures[k].rgb.data(), s.mesh.textures[k].rgb.size());
+    }
+    if (n.compare(0, 13, "texture_size:") == 0) {
+        const size_t k = (size_t)std::strtoul(n.c_str() + 13, nullptr, 10);
+        if (k >= s.mesh.textures.size()) return RTAMD_ERR_INVALID;
+        return set(&s.mesh.textures[k].width, 2);
+    }
     return RTAMD_ERR_INVALID;
 }
 

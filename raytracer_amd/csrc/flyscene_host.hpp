@@ -19,6 +19,14 @@ namespace rtamd {
 struct NamedMaterial {
     std::string name;
     rtamd_material m;
+    std::string diffuse_texture; // Mtl::diffuse_tex_filename (map_kd), empty = none
+};
+
+// texturedatas[filename] of the reference, src/flyscene.cpp:52-71
+struct HostTexture {
+    std::string file;
+    int32_t width = 0, height = 0;
+    std::vector<float> rgb;
 };
 
 // What Tucano::Mesh holds after MeshImporter::loadObjFile.
@@ -28,13 +36,18 @@ struct HostMesh {
     std::vector<int32_t> face_vertex; // 3 per face, in file order
     std::vector<float> face_normal;   // 3 per face, Face::normal
     std::vector<int32_t> face_material;
+    std::vector<float> face_texcoord; // 6 per face (Face::texcoord), empty when the mesh has no texture coordinates
     std::vector<NamedMaterial> materials;
+    std::vector<HostTexture> textures;
+    std::vector<int32_t> material_texture; // per material: index into textures, -1 none
     int32_t num_vertices() const { return (int32_t)(vertices.size() / 3); }
     int32_t num_faces() const { return (int32_t)(face_vertex.size() / 3); }
 };
 
 bool load_obj(const std::string &path, HostMesh &mesh, std::string &error);
 bool load_mtl(const std::string &path, std::vector<NamedMaterial> &materials);
+bool load_ppm_texture(const std::string &path, HostTexture &tex, std::string &error); // utils/ppmIO.hpp:36-86
+bool load_material_textures(HostMesh &mesh, std::string &error);                       // src/flyscene.cpp:52-71
 void finish_mesh(HostMesh &mesh, bool have_normals);
 bool write_ppm(const std::string &path, const float *rgb, int width, int height);
 

@@ -480,9 +480,9 @@ __global__ __launch_bounds__(256) void compact_kernel(DeviceScene sc, FrameConst
         bool go = false;
         if (spawn && hit && tri >= 0) {
             const int face = __float_as_int(sc.tris[tri * 4 + 1].w);
-            const int mat = __float_as_int(sc.shade[face * 6 + 5].y);
+            const int mat = __float_as_int(sc.shade[face * kShadeRecordQuads + 5].y);
             if (mat >= 0 && mat < sc.num_materials) {
-                const float *mp = sc.materials + 10 * mat;
+                const float *mp = sc.materials + kMaterialFloats * mat;
                 go = mp[6] > fc.refl_thresh || mp[7] > fc.refl_thresh || mp[8] > fc.refl_thresh; // :631-632
             }
         }
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void compact_kernel(DeviceScene sc, FrameConst
         const V3 hp = o + t * d; // hitPoint, :709,771
         if (go) {
             const int face = __float_as_int(sc.tris[tri * 4 + 1].w);
-            const float4 s4 = sc.shade[face * 6 + 4], s5 = sc.shade[face * 6 + 5];
+            const float4 s4 = sc.shade[face * kShadeRecordQuads + 4], s5 = sc.shade[face * kShadeRecordQuads + 5];
             const V3 fn = mk(s4.z, s4.w, s5.x);
             const V3 refl = normalized(d - (2 * dot(d, fn)) * fn); // :785 then :635
             const V3 no = hp + fc.bounce_off * refl;               // :636
@@ -630,15 +630,15 @@ __global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, FrameConst f
         local = mk(0.7f, 0.9f, 0.0f); // sphere, :463-465
     } else {
         const int face = __float_as_int(sc.tris[tri * 4 + 1].w);
-        const float4 s0 = sc.shade[face * 6 + 0], s1 = sc.shade[face * 6 + 1], s2 = sc.shade[face * 6 + 2];
-        const float4 s3 = sc.shade[face * 6 + 3], s4 = sc.shade[face * 6 + 4], s5 = sc.shade[face * 6 + 5];
+        const float4 s0 = sc.shade[face * kShadeRecordQuads + 0], s1 = sc.shade[face * kShadeRecordQuads + 1], s2 = sc.shade[face * kShadeRecordQuads + 2];
+        const float4 s3 = sc.shade[face * kShadeRecordQuads + 3], s4 = sc.shade[face * kShadeRecordQuads + 4], s5 = sc.shade[face * kShadeRecordQuads + 5];
         const V3 v0 = mk(s0.x, s0.y, s0.z), v1 = mk(s0.w, s1.x, s1.y), v2 = mk(s1.z, s1.w, s2.x);
         const V3 n0 = mk(s2.y, s2.z, s2.w), n1 = mk(s3.x, s3.y, s3.z), n2 = mk(s3.w, s4.x, s4.y);
         const int mat = __float_as_int(s5.y);
         if (mat < 0 || mat >= sc.num_materials) {
             local = mk(0.5f, 0.5f, 0.5f); // :469-472
         } else {
-            const float *mp = sc.materials + 10 * mat;
+            const float *mp = sc.materials + kMaterialFloats * mat;
             const V3 ka = mk(mp[0], mp[1], mp[2]), kd = mk(mp[3], mp[4], mp[5]);
             ks = mk(mp[6], mp[7], mp[8]);
             const float shininess = mp[9];
@@ -647,13 +647,30 @@ __global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, FrameConst f
             const float a02 = norm(cross(v0 - P, v2 - P)) * 0.5f;
             const float a01 = norm(cross(v0 - P, v1 - P)) * 0.5f;
             const V3 N = normalized((a12 * n0 + a02 * n1) + a01 * n2);
+            // Texture branch, :476-481,516-542.  The weights are the absolute sub-triangle areas, not divided
+            // by the face area; uacc and vacc of the reference are floors of fractional parts, always 0, so
+            // its "interpolation" is the one texel at (projU, projV).  The reference indexes unchecked; an
+            // index outside the image (undefined there) is clamped to it.
+            V3 albedo = kd;
+            const int tex = sc.num_textures > 0 ? __float_as_int(mp[10]) : -1;
+            if (tex >= 0) {
+                const float4 s6 = sc.shade[face * kShadeRecordQuads + 6];
+                const float u = (a12 * s5.z + a02 * s6.x) + a01 * s6.z;
+                const float v = (a12 * s5.w + a02 * s6.y) + a01 * s6.w;
+                const int first = sc.tex_info[4 * tex], w = sc.tex_info[4 * tex + 1], h = sc.tex_info[4 * tex + 2];
+                const double idx = (double)floorf(v * (float)h) * (double)w + (double)floorf(u * (float)w);
+                const double last = (double)w * (double)h - 1.0;
+                const int at = !(idx >= 0.0) ? 0 : idx > last ? (int)last : (int)idx;
+                const float *tx = sc.texels + 3 * (size_t)(first + at);
+                albedo = mk(tx[0], tx[1], tx[2]);
+            }
             local = mk(0.0f, 0.0f, 0.0f);
             for (int l = 0; l < sc.num_lights; ++l) {
                 const V3 lp = mk(sc.light_pos[3 * l], sc.light_pos[3 * l + 1], sc.light_pos[3 * l + 2]);
                 const V3 L = normalized(lp - P);                          // :507
                 const V3 ambient = cmul(LI, ka);                          // :510
                 const float cos1 = fmaxf(0.0f, dot(L, N));                // :513
-                const V3 diffuse = cos1 * cmul(LI, kd);                   // :514
+                const V3 diffuse = cos1 * cmul(LI, albedo);               // :514 / :541
                 const V3 E = normalized(ro - P);                          // :545
                 const V3 R = normalized(-L + (2.f * dot(L, N)) * N);      // :546
                 const float cos2 = fmaxf(0.0f, dot(R, E));                // :548

@@ -30,11 +30,13 @@ def _iptr(a):
 
 class Flyscene:
     def __init__(self, model=None, arrays=None, lights=None, hard_shadow=True, soft_points=12, soft_radius=0.3,
-                 spheres=(), normalize_model=True, output="result.ppm", max_leaf_faces=0, sah_bins=0):
+                 spheres=(), normalize_model=True, output="result.ppm", max_leaf_faces=0, sah_bins=0, textures=None):
         """model: OBJ path (default: the reference's resources/models/bunny.obj, src/flyscene.cpp:39).
         arrays: (vertices[nv,3], normals[nv,3] or None, faces[nf,3], face_material[nf], materials) with
         materials a list of dicts ka/kd/ks/shininess.  lights: list of (x, y, z) or (x, y, z, r, g, b);
-        None keeps the reference's single light at (-1, 1, 1)."""
+        None keeps the reference's single light at (-1, 1, 1).  textures (with arrays only; an OBJ brings its
+        own through vt / map_kd): dict face_texcoords[nf,3,2], material_textures[nm] (-1 = none), images = list of
+        [h,w,3] float arrays in the row order of the reference's texturedatas (file rows flipped)."""
         self.lib = L.lib()
         h = C.c_void_p()
         L.check(self.lib.rtfly_create(C.byref(h)), "rtfly_create")
@@ -56,6 +58,15 @@ class Flyscene:
                 marr[i].shininess = m["shininess"]
             L.check(self.lib.rtfly_set_model_arrays(self.h, _fptr(v), nptr, len(v), _iptr(f), _iptr(fm), len(f), marr, len(mats)),
                     "rtfly_set_model_arrays")
+            if textures is not None:
+                tc = np.ascontiguousarray(textures["face_texcoords"], np.float32).reshape(len(f), 6)
+                mt = np.ascontiguousarray(textures["material_textures"], np.int32).reshape(len(mats))
+                imgs = [np.ascontiguousarray(im, np.float32) for im in textures["images"]]
+                tarr = (L.Texture * max(1, len(imgs)))()
+                for i, im in enumerate(imgs):
+                    tarr[i].height, tarr[i].width = im.shape[0], im.shape[1]
+                    tarr[i].rgb = _fptr(im)
+                L.check(self.lib.rtfly_set_texture_arrays(self.h, _fptr(tc), _iptr(mt), tarr, len(imgs)), "rtfly_set_texture_arrays")
         elif model is not None:
             L.check(self.lib.rtfly_set_model(self.h, os.fsencode(model)), "rtfly_set_model")
         if lights is not None:
@@ -213,6 +224,33 @@ class Flyscene:
                 a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n.value,)).astype(dt, copy=True)
             out[name] = a.reshape(shape)
         return out
+
+
+def _get_array(fly, name, dt):
+    ptr = C.c_void_p()
+    n = C.c_int64()
+    L.check(fly.lib.rtfly_get_array(fly.h, name.encode(), C.byref(ptr), C.byref(n)), "rtfly_get_array")
+    if n.value == 0 or not ptr.value:
+        return np.zeros(0, dt)
+    ct = C.c_float if dt == np.float32 else C.c_int32
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(n.value,)).astype(dt, copy=True)
+
+
+def texture_arrays(fly):
+    """What the texture branch of shadeOffFace reads (src/flyscene.cpp:476-481,502,519-533), as numpy copies:
+    face_texcoords[nf,3,2] (empty without `vt`), material_textures[nm], images (texturedatas)."""
+    out = {"face_texcoords": _get_array(fly, "face_texcoords", np.float32).reshape(-1, 3, 2),
+           "material_textures": _get_array(fly, "material_textures", np.int32), "images": []}
+    k = 0
+    while True:
+        ptr = C.c_void_p()
+        n = C.c_int64()
+        if fly.lib.rtfly_get_array(fly.h, ("texture_size:%d" % k).encode(), C.byref(ptr), C.byref(n)) != L.OK:
+            break
+        w, h = _get_array(fly, "texture_size:%d" % k, np.int32)
+        out["images"].append(_get_array(fly, "texture:%d" % k, np.float32).reshape(h, w, 3))
+        k += 1
+    return out
 
 
 def write_ppm(path, rgb):

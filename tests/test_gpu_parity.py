@@ -21,7 +21,8 @@ from raytracer_amd import tiles, workloads
 
 pytestmark = pytest.mark.gpu
 
-ALL = ["reflect_test", "reflect_test_2", "shadowmodel", "NthTest", "glass", "toy", "toy_on_plane", "dodgeColorTest", "bunny"]
+ALL = ["reflect_test", "reflect_test_2", "shadowmodel", "NthTest", "glass", "toy", "toy_on_plane", "dodgeColorTest", "bunny",
+       "textured_quad"]
 
 
 def assert_parity(r, exact_faces=True):
@@ -54,6 +55,42 @@ def test_against_committed_golden_vectors(path):
     assert np.abs(got["rgb"] - g["rgb"])[clean].max() <= PIXEL_TOL
     st = got["stats"]
     assert [st.rays_primary, st.rays_shadow, st.rays_bounce] == g["rays_nanfree"].tolist()
+
+
+def test_texture_branch_from_arrays_matches_obj_path_and_oracle():
+    """shadeOffFace's texture branch (flyscene.cpp:516-542): texel picked by area-weighted, un-normalised
+    texture coordinates; faces without `vt` carry (-1,-1) and land on the clamped first texel."""
+    from raytracer_amd.flyscene import texture_arrays
+
+    fly, orc = make_pair("textured_quad", width=128, height=128)
+    r = compare(fly, orc, 128, 128)
+    assert_parity(r)
+    # texels of both images must show up in the frame: many distinct colours on the two textured faces
+    quad = np.isin(r["got"]["face_id"], (0, 1))
+    assert len(np.unique(r["got"]["rgb"][quad].round(4), axis=0)) > 50
+    # the same scene handed over as arrays + textures renders the same image bit for bit
+    a = fly.arrays()
+    t = texture_arrays(fly)
+    mats = [dict(ka=m[0:3], kd=m[3:6], ks=m[6:9], shininess=m[9]) for m in a["materials"].reshape(-1, 10)]
+    again = R.Flyscene(arrays=(a["raw_vertices"].reshape(-1, 3), a["raw_normals"].reshape(-1, 3), a["face_vertex_ids"].reshape(-1, 3),
+                               a["face_material_ids"], mats), textures=t, output="").initialize(128, 128)
+    assert np.array_equal(again.render()["rgb"].view(np.uint32), r["got"]["rgb"].view(np.uint32))
+    # without the textures the material colour is used and the frame differs
+    plain = R.Flyscene(arrays=(a["raw_vertices"].reshape(-1, 3), a["raw_normals"].reshape(-1, 3), a["face_vertex_ids"].reshape(-1, 3),
+                               a["face_material_ids"], mats), output="").initialize(128, 128)
+    assert np.abs(plain.render()["rgb"] - r["got"]["rgb"])[quad].max() > 0.05
+
+
+def test_single_stream_flag_and_many_live_scenes():
+    """Frames with reflections use two process-wide side streams; several reflective scenes alive at once must
+    not add streams (hardware queues are few), and RTAMD_FLAG_SINGLE_STREAM must give the same image."""
+    flies = [make_pair("reflect_test", width=64, height=64)[0] for _ in range(4)]
+    frames = [f.render()["rgb"] for f in flies]
+    for fr in frames[1:]:
+        assert np.array_equal(fr.view(np.uint32), frames[0].view(np.uint32))
+    flies[0].set_params(flags=L.FLAG_SINGLE_STREAM)
+    assert np.array_equal(flies[0].render()["rgb"].view(np.uint32), frames[0].view(np.uint32))
+    assert flies[0].render()["stats"].rays_bounce > 0
 
 
 def test_non_square_and_ragged_sizes():

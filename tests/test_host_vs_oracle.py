@@ -13,7 +13,8 @@ from oracle.oracle_py import OracleScene
 import raytracer_amd as R
 from raytracer_amd import _lib as L
 
-SCENES = ["reflect_test", "reflect_test_2", "shadowmodel", "NthTest", "glass", "toy", "toy_on_plane", "dodgeColorTest", "bunny"]
+SCENES = ["reflect_test", "reflect_test_2", "shadowmodel", "NthTest", "glass", "toy", "toy_on_plane", "dodgeColorTest", "bunny",
+          "textured_quad"]
 KEYS = ["raw_vertices", "raw_normals", "vertices", "normals", "face_vertex_ids", "face_normals", "face_origin_distance",
         "face_material_ids", "materials", "light_samples", "model_matrix"]
 
@@ -30,6 +31,32 @@ def test_flattened_scene_is_bit_identical(name):
     ref = OracleScene(scene_path(name)).arrays()
     for k in KEYS:
         assert same_bits(got[k], ref[k]), "%s: %s differs" % (name, k)
+
+
+def test_texture_inputs_are_bit_identical(tmp_path):
+    """`vt` / texture ids of `f` records / map_kd / ASCII PPM with flipped rows (objimporter.hpp:51-79,222-256;
+    mtlIO.hpp:122-125; ppmIO.hpp:36-86): host loader vs oracle loader."""
+    from raytracer_amd.flyscene import texture_arrays
+
+    fly = R.Flyscene(model=scene_path("textured_quad"), output="").initialize(16, 16, upload=False)
+    got, ref = texture_arrays(fly), OracleScene(scene_path("textured_quad")).texture_arrays()
+    assert same_bits(got["face_texcoords"], ref["face_texcoords"]) and got["face_texcoords"].shape == (5, 3, 2)
+    assert got["material_textures"].tolist() == ref["material_textures"].tolist() == [0, 1, -1]
+    assert len(got["images"]) == len(ref["images"]) == 2
+    for a, b in zip(got["images"], ref["images"]):
+        assert same_bits(a, b)
+    # checker.ppm: 8x4, first value of the file's LAST row comes first (40/255, 180/255, 255/255)
+    assert got["images"][0].shape == (4, 8, 3)
+    assert got["images"][0][0, 0].tolist() == [np.float32(40) / np.float32(255), np.float32(180) / np.float32(255), np.float32(1)]
+    # faces of a textured group whose records carry no texture id keep the default (-1,-1)
+    assert (got["face_texcoords"][3] == -1).all()
+    # a scene without `vt` has no texture coordinates at all, and a missing image is an error, not a silent skip
+    assert texture_arrays(R.Flyscene(model=scene_path("toy"), output="").initialize(8, 8, upload=False))["face_texcoords"].size == 0
+    import shutil
+    for f in ("textured_quad.obj", "textured_quad.mtl", "checker.ppm"):
+        shutil.copy(scene_path(f[:-4])[:-4] + f[-4:], tmp_path / f)
+    with pytest.raises(L.RtamdError):
+        R.Flyscene(model=str(tmp_path / "textured_quad.obj"), output="").initialize(8, 8, upload=False)
 
 
 def test_face_count_and_order_follow_the_file():

@@ -19,6 +19,7 @@ from oracle.oracle_py import OracleScene  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 SMALL = ["reflect_test", "reflect_test_2", "shadowmodel", "NthTest", "glass"]
+TEXTURED = ["textured_quad"]  # synthetic scene of this repository: vt + map_kd + ASCII PPM textures
 LARGE = ["toy", "toy_on_plane", "dodgeColorTest", "bunny"]
 
 
@@ -44,6 +45,9 @@ def one(name, size, full):
     for k in ("vertices", "normals", "face_normals", "face_origin_distance", "face_vertex_ids", "face_material_ids", "light_samples",
               "materials"):
         out["sha256_" + k] = np.array(digest(a[k]))
+    t = s.texture_arrays()
+    out["sha256_face_texcoords"] = np.array(digest(t["face_texcoords"]))
+    out["sha256_textures"] = np.array(digest(np.concatenate([im.reshape(-1) for im in t["images"]]) if t["images"] else np.zeros(0, np.float32)))
     if full:
         boxes, info = s.bvh_dump()
         out.update({"t": r["t"], "light": r["light"], "bvh_boxes": boxes, "bvh_info": info, "face_order": s.bvh_face_order(),
@@ -58,4 +62,7 @@ if __name__ == "__main__":
         one(n, 64, True)
         one(n, 256, False)
     for n in LARGE:
+        one(n, 256, False)
+    for n in TEXTURED:
+        one(n, 64, True)
         one(n, 256, False)
