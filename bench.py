@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--row-tile", type=int, default=16)
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH: faces per leaf (0 = library default)")
     ap.add_argument("--sah-bins", type=int, default=0, help="BVH: SAH bins (0 = library default)")
+    ap.add_argument("--shadow-rays", type=int, default=0, help="0 = candidate grids when possible, 1 = shadow rays walk the BVH")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample; 0 = skip")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events in the timed region")
     return ap.parse_args()
@@ -154,7 +155,7 @@ def main():
     name = a.workload or ("bunny_1080p" if world == 1 else "field_4k")
     w = workloads.get(name)
     t0 = time.time()
-    fly, params, cam = workloads.make_flyscene(w, max_leaf_faces=a.max_leaf, sah_bins=a.sah_bins)
+    fly, params, cam = workloads.make_flyscene(w, max_leaf_faces=a.max_leaf, sah_bins=a.sah_bins, shadow_rays=a.shadow_rays)
     info = fly.info()
     init_s = time.time() - t0
     W, H = w["width"], w["height"]
@@ -235,6 +236,7 @@ def main():
                 "samples_per_light": 1 + w["soft_points"], "max_reflections": w["max_reflections"],
                 "rays_per_frame": {"primary": int(rays[0].item()), "shadow": int(rays[1].item()), "bounce": int(rays[2].item())},
                 "parallelism": "row tiles of %d rows round-robin over %d GPU(s), one gather" % (a.row_tile, world),
+                "shadow_rays": "per-sample candidate grids (%d face references)" % info.shadow_grid_entries if info.shadow_grid_entries else "BVH walk",
                 "bvh": {"nodes": int(info.num_nodes), "leaves": int(info.num_leaves), "depth": int(info.depth),
                         "build_ms": round(float(info.build_ms), 1), "device_MB": round(info.device_bytes / 1e6, 2)},
                 "scene_init_s": round(init_s, 2),
@@ -251,7 +253,7 @@ def main():
             byts = [wl[0] * BYTES_BOX + wl[1] * BYTES_PLANE + wl[2] * BYTES_EDGE,
                     wl[3] * BYTES_BOX + wl[4] * BYTES_PLANE + wl[5] * BYTES_EDGE]
             k = 0 if kmax[0].item() >= kmax[1].item() else 1
-            kname = ("walk_kernel<closest hit>", "walk_kernel<shadow>")[k]
+            kname = ("walk_kernel<closest hit>", "shadow_grid_kernel" if info.shadow_grid_entries else "walk_kernel<shadow>")[k]
             per_launch_ms = (ms_trace, ms_shadow)[k]
             flops_launch = flops[k] / launches_per_frame[k]
             bytes_launch = byts[k] / launches_per_frame[k]
@@ -260,8 +262,8 @@ def main():
                                "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None,
                                "avg_launch_ms": round(per_launch_ms, 4), "launches_per_frame": launches_per_frame[k],
                                "share_of_frame": round(kmax[k].item() / max(kmax[6].item(), 1e-9), 3)}
-            traffic, traffic_src = pmc_traffic(name, ("walk_kernel<1, false>", "walk_kernel<2, false>")[k] if name != "field_4k" else
-                                               ("walk_kernel<0, false>", "walk_kernel<2, false>")[k])
+            shadow_key = "shadow_grid_kernel<false>" if info.shadow_grid_entries else "walk_kernel<2, false>"
+            traffic, traffic_src = pmc_traffic(name, ("walk_kernel<1, false>" if w["max_reflections"] > 0 else "walk_kernel<0, false>", shadow_key)[k])
             out["roofline"]["traffic"] = None if traffic is None else round(traffic)
             if traffic is not None:
                 out["roofline"]["traffic_unit"] = "bytes/launch at the L2's memory side, (2*FETCH_SIZE + WRITE_SIZE) KiB, from profiles/" + traffic_src

@@ -84,10 +84,14 @@ typedef struct {
     int32_t num_textures;
 } rtamd_scene_desc;
 
+#define RTAMD_SHADOW_RAYS_AUTO 0 /* per-sample candidate grids when every sample direction allows it   */
+#define RTAMD_SHADOW_RAYS_TREE 1 /* shadow rays walk the BVH like every other ray                       */
+
 typedef struct {
     int32_t max_leaf_faces; /* 1..15; 0 = default (4)                                              */
     int32_t sah_bins;       /* 4..64; 0 = default (16)                                             */
-    int32_t reserved[6];
+    int32_t shadow_rays;    /* RTAMD_SHADOW_RAYS_*                                                 */
+    int32_t reserved[5];
 } rtamd_build_params;
 
 /* What tracePixels/screenToWorld read from Tucano::Camera (camera.hpp:84,118-121,158-181). */
@@ -157,8 +161,9 @@ typedef struct {
     int32_t depth;
     int32_t device;           /* HIP device ordinal                                               */
     uint64_t device_bytes;    /* scene data resident in HBM                                       */
-    float build_ms;           /* host BVH build                                                   */
+    float build_ms;           /* host BVH (and shadow grid) build                                 */
     float upload_ms;
+    uint64_t shadow_grid_entries; /* face references in the shadow-ray grids, 0 = tree walk        */
 } rtamd_scene_info;
 
 const char *rtamd_last_error(void);

@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(_HERE, "lib", "librtamd.s
 OK, ERR_INVALID, ERR_HIP, ERR_LIMIT, ERR_NO_DEVICE = 0, 1, 2, 3, 4
 FACE_SPHERE, FACE_MISS = -1, -2
 FLAG_COUNT_WORK, FLAG_TIME_KERNELS, FLAG_SINGLE_STREAM = 1, 2, 4
+SHADOW_RAYS_AUTO, SHADOW_RAYS_TREE = 0, 1
 
 
 class Material(C.Structure):
@@ -41,7 +42,7 @@ class SceneDesc(C.Structure):
 
 
 class BuildParams(C.Structure):
-    _fields_ = [("max_leaf_faces", C.c_int32), ("sah_bins", C.c_int32), ("reserved", C.c_int32 * 6)]
+    _fields_ = [("max_leaf_faces", C.c_int32), ("sah_bins", C.c_int32), ("shadow_rays", C.c_int32), ("reserved", C.c_int32 * 5)]
 
 
 class Camera(C.Structure):
@@ -85,7 +86,7 @@ class SceneInfo(C.Structure):
     _fields_ = [
         ("num_faces", C.c_int32), ("num_device_faces", C.c_int32), ("num_nodes", C.c_int32), ("num_leaves", C.c_int32),
         ("depth", C.c_int32), ("device", C.c_int32), ("device_bytes", C.c_uint64), ("build_ms", C.c_float),
-        ("upload_ms", C.c_float),
+        ("upload_ms", C.c_float), ("shadow_grid_entries", C.c_uint64),
     ]
 
     def as_dict(self):

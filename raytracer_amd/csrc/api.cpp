@@ -19,6 +19,7 @@
 
 #include "../../include/rtamd.h"
 #include "bvh.hpp"
+#include "shadow_grid.hpp"
 #include "device_types.h"
 #include "kernels.h"
 
@@ -64,6 +65,7 @@ struct rtamd_scene {
     int num_cus = 256;
     void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_materials = nullptr;
     void *d_light_pos = nullptr, *d_samples = nullptr, *d_spheres = nullptr, *d_texels = nullptr, *d_tex_info = nullptr;
+    void *d_grid_headers = nullptr, *d_grid_cells = nullptr, *d_grid_entries = nullptr;
     DeviceScene ds{};
     Workspace ws{};
     void *ws_block = nullptr;
@@ -288,6 +290,9 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
         return fail(RTAMD_ERR_LIMIT, "BVH needs %d traversal stack entries, the kernels hold %d", bvh.stack_need, kStackEntries);
     }
     const bool textured = d->num_textures > 0 && d->face_texcoords && d->material_textures && d->textures;
+    ShadowGrids grids;
+    if (!(build && build->shadow_rays == RTAMD_SHADOW_RAYS_TREE))
+        build_shadow_grids(bvh, d->light_samples, d->num_lights * d->samples_per_light, grids);
     std::vector<ShadeRecord> shade((size_t)d->num_faces);
     for (int32_t f = 0; f < d->num_faces; ++f) {
         ShadeRecord &r = shade[f];
@@ -339,6 +344,9 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     if (rc == RTAMD_OK) rc = upload(&s->d_spheres, spheres, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_texels, texels, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_tex_info, tex_info, &bytes);
+    if (rc == RTAMD_OK) rc = upload(&s->d_grid_headers, grids.headers, &bytes);
+    if (rc == RTAMD_OK) rc = upload(&s->d_grid_cells, grids.cell_start, &bytes);
+    if (rc == RTAMD_OK) rc = upload(&s->d_grid_entries, grids.entries, &bytes);
     if (rc != RTAMD_OK) {
         rtamd_scene_destroy(s);
         return rc;
@@ -355,6 +363,11 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     s->ds.texels = (const float *)s->d_texels;
     s->ds.tex_info = (const int32_t *)s->d_tex_info;
     s->ds.num_textures = textured ? d->num_textures : 0;
+    s->ds.grid_headers = (const float4 *)s->d_grid_headers;
+    s->ds.grid_cells = (const int32_t *)s->d_grid_cells;
+    s->ds.grid_entries = (const int2 *)s->d_grid_entries;
+    s->ds.use_grids = grids.usable ? 1 : 0;
+    s->info.shadow_grid_entries = grids.usable ? (uint64_t)grids.entries.size() : 0;
     s->ds.num_lights = d->num_lights;
     s->ds.spl = d->samples_per_light;
     s->ds.num_spheres = d->num_spheres;
@@ -391,7 +404,8 @@ int rtamd_reference_face_rank(const rtamd_scene_desc *d, int32_t *rank_out) {
 int rtamd_scene_destroy(rtamd_scene *s) {
     if (!s) return RTAMD_OK;
     void *bufs[] = {s->d_nodes, s->d_tris,  s->d_shade,  s->d_materials, s->d_light_pos, s->d_samples,
-                    s->d_spheres, s->d_texels, s->d_tex_info, s->ws_block, s->d_rgb, s->d_face};
+                    s->d_spheres, s->d_texels, s->d_tex_info, s->d_grid_headers, s->d_grid_cells, s->d_grid_entries,
+                    s->ws_block, s->d_rgb, s->d_face};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     for (TimedLaunch &t : s->events) {

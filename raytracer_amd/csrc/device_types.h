@@ -23,6 +23,11 @@ struct DeviceScene {
     const float4 *spheres;    // center, radius
     int32_t num_lights, spl, num_spheres, num_materials;
     int32_t num_textures; // 0 also when the mesh has no texture coordinates
+    // shadow-ray candidate grids (shadow_grid.hpp), one per light sample; use_grids = 0: shadow rays walk the tree
+    const float4 *grid_headers;   // 4 x float4 per ShadowGridHeader
+    const int32_t *grid_cells;    // cell-start array of all grids
+    const int2 *grid_entries;     // (TriRecord index, zmax bits)
+    int32_t use_grids;
 };
 
 // Per-launch constants (camera + the reference's macros).

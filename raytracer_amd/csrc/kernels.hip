@@ -443,6 +443,75 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
 }
 
 // ---------------------------------------------------------------------------------------------
+// Shadow rays through the candidate grids (shadow_grid.hpp).  All shadow rays of one light sample are
+// parallel (their direction is the sample's position, src/flyscene.cpp:884), so the faces that can occlude a
+// point are found by projecting the point along that direction into a 2D grid built once per scene.  One wave
+// = 64 consecutive hits x one sample; a lane looks up its cell and runs the exact plane + three-edge test
+// (src/flyscene.cpp:752-789, same arithmetic as the tree walk) over the cell's list, which is sorted by the
+// faces' farthest extent along the direction: the scan ends at the first face that lies wholly behind the
+// ray's origin, or at the first face that blocks the sample.
+// ---------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ __launch_bounds__(64) void shadow_grid_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth) {
+    const int lane = (int)threadIdx.x;
+    const int nshadow = sc.num_lights * sc.spl;
+    const int nhits = ws.stage[stage].hits;
+    const int chunks = (nhits + 63) >> 6;
+    const int ngroups = chunks * nshadow;
+    unsigned w_box = 0, w_plane = 0, w_edge = 0;
+    for (int group = (int)blockIdx.x; group < ngroups; group += (int)gridDim.x) {
+        const int chunk = group / nshadow, sample = group - chunk * nshadow;
+        const int hit = (chunk << 6) + lane;
+        if (hit >= nhits) continue;
+        const float *hp = ws.hits[depth & 1].p;
+        const V3 o = mk(hp[hit], hp[(size_t)ws.capacity + hit], hp[2 * (size_t)ws.capacity + hit]);
+        const V3 d = mk(sc.samples[3 * sample], sc.samples[3 * sample + 1], sc.samples[3 * sample + 2]);
+        bool blocked = false;
+        // intersects(): spheres first (:673-676)
+        float tbest = FLT_MAX;
+        if (sc.num_spheres > 0 && spheres_hit(sc, o, d, fc.t_eps, tbest)) blocked = true;
+        if (!blocked) {
+            const float4 g0 = sc.grid_headers[sample * 4 + 0], g1 = sc.grid_headers[sample * 4 + 1];
+            const float4 g2 = sc.grid_headers[sample * 4 + 2], g3 = sc.grid_headers[sample * 4 + 3];
+            // header: U (g0.xyz), V (g0.w g1.xy), W (g1.zw g2.x), u0 v0 inv_cell (g2.yzw), res first_cell (g3.xy)
+            const float u = o.x * g0.x + (o.y * g0.y + o.z * g0.z);
+            const float v = o.x * g0.w + (o.y * g1.x + o.z * g1.y);
+            const float z = o.x * g1.z + (o.y * g1.w + o.z * g2.x);
+            const float fx = floorf((u - g2.y) * g2.w), fy = floorf((v - g2.z) * g2.w);
+            const int res = __float_as_int(g3.x), first_cell = __float_as_int(g3.y);
+            if (COUNT) ++w_box;
+            if (fx >= 0.0f && fy >= 0.0f && fx < (float)res && fy < (float)res) {
+                const int cell = first_cell + (int)fy * res + (int)fx;
+                const int begin = sc.grid_cells[cell], end = sc.grid_cells[cell + 1];
+                for (int e = begin; e < end; ++e) {
+                    const int2 ent = sc.grid_entries[e];
+                    if (__int_as_float(ent.y) < z) break; // this face and all later ones lie behind the origin
+                    const int i = ent.x;
+                    const float4 pn = sc.tris[i * 4 + 0];
+                    if (COUNT) ++w_plane;
+                    const V3 n = mk(pn.x, pn.y, pn.z);
+                    const float t = (pn.w - dot(o, n)) / dot(d, n);
+                    if (!(t >= fc.t_eps && t <= tbest)) continue; // also rejects NaN (see file header)
+                    const float4 p0 = sc.tris[i * 4 + 1];
+                    const float4 p1 = sc.tris[i * 4 + 2];
+                    const float4 p2 = sc.tris[i * 4 + 3];
+                    if (COUNT) ++w_edge;
+                    const V3 v0 = mk(p0.x, p0.y, p0.z), v1 = mk(p1.x, p1.y, p1.z), v2 = mk(p2.x, p2.y, p2.z);
+                    const V3 at = o + t * d;
+                    if (dot(cross(v1 - v0, at - v0), n) < 0) continue;
+                    if (dot(cross(v2 - v1, at - v1), n) < 0) continue;
+                    if (dot(cross(v0 - v2, at - v2), n) < 0) continue;
+                    blocked = true;
+                    break;
+                }
+            }
+        }
+        ws.clear[depth & 1][sample * ws.capacity + hit] = blocked ? 0 : 1;
+    }
+    if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 1);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Compaction: ray slots that hit something -> dense hit list (slot order inside a workgroup, one atomic
 // per workgroup and list: atomics on one address serialise in L2, so a workgroup covers up to 2048 slots).  Also writes the hit point, the primary planes (face id, distance), the colour
 // of primary rays that hit nothing (src/flyscene.cpp:650-658), and -- the reflection set-up of traceRay,
@@ -791,6 +860,13 @@ void launch_walk_shadow(bool count, const DeviceScene &sc, const FrameConst &fc,
     const int nshadow = sc.num_lights * sc.spl;
     if (nshadow <= 0) return;
     const int blocks = walk_grid((long long)(fc.tiles_x * fc.tiles_y) * nshadow);
+    if (sc.use_grids) {
+        if (count)
+            shadow_grid_kernel<true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth);
+        else
+            shadow_grid_kernel<false><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth);
+        return;
+    }
     if (count)
         walk_kernel<kShadow, true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, 0);
     else

@@ -93,6 +93,29 @@ def test_single_stream_flag_and_many_live_scenes():
     assert flies[0].render()["stats"].rays_bounce > 0
 
 
+@pytest.mark.parametrize("name", ["NthTest", "toy_on_plane", "bunny", "textured_quad"])
+def test_shadow_grids_and_tree_walk_agree(name):
+    """Shadow rays take per-sample candidate grids by default (all rays of a sample are parallel); forcing them
+    through the BVH must give the same frame bit for bit: both run the same exact face test."""
+    kw = dict(model=scene_path(name), output="", lights=[(-1, 1, 1), (0.0, 1.0, 1.5), (1.5, 1.0, 1e-16)])
+    a = R.Flyscene(**kw).initialize(96, 96)
+    b = R.Flyscene(shadow_rays=L.SHADOW_RAYS_TREE, **kw).initialize(96, 96)
+    assert a.info().shadow_grid_entries > 0 and b.info().shadow_grid_entries == 0
+    ra, rb = a.render(), b.render()
+    assert np.array_equal(ra["rgb"].view(np.uint32), rb["rgb"].view(np.uint32))
+    assert np.array_equal(ra["face_id"], rb["face_id"])
+    sa, sb = ra["stats"], rb["stats"]
+    assert (sa.rays_shadow, sa.rays_bounce, sa.hits) == (sb.rays_shadow, sb.rays_bounce, sb.hits)
+    assert sa.rays_shadow > 0
+
+
+def test_degenerate_sample_direction_falls_back_to_the_tree():
+    # a light at the origin gives a zero shadow-ray direction (its hard-shadow sample): no grid can be built for it
+    fly, orc = make_pair("glass", width=48, height=48, lights=[(0.0, 0.0, 0.0)], soft_points=0)
+    assert fly.info().shadow_grid_entries == 0
+    assert_parity(compare(fly, orc, 48, 48))
+
+
 def test_non_square_and_ragged_sizes():
     fly, orc = make_pair("toy", width=200, height=120)
     assert_parity(compare(fly, orc, 200, 120))
