@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH: faces per leaf (0 = library default)")
     ap.add_argument("--sah-bins", type=int, default=0, help="BVH: SAH bins (0 = library default)")
     ap.add_argument("--shadow-rays", type=int, default=0, help="0 = candidate grids when possible, 1 = shadow rays walk the BVH")
+    ap.add_argument("--primary-rays", type=int, default=0, help="0 = screen binning, 1 = primary rays walk the BVH")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample; 0 = skip")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket launches with HIP events in the timed region")
     return ap.parse_args()
@@ -155,7 +156,7 @@ def main():
     name = a.workload or ("bunny_1080p" if world == 1 else "field_4k")
     w = workloads.get(name)
     t0 = time.time()
-    fly, params, cam = workloads.make_flyscene(w, max_leaf_faces=a.max_leaf, sah_bins=a.sah_bins, shadow_rays=a.shadow_rays)
+    fly, params, cam = workloads.make_flyscene(w, max_leaf_faces=a.max_leaf, sah_bins=a.sah_bins, shadow_rays=a.shadow_rays, primary_rays=a.primary_rays)
     info = fly.info()
     init_s = time.time() - t0
     W, H = w["width"], w["height"]

@@ -84,6 +84,8 @@ typedef struct {
     int32_t num_textures;
 } rtamd_scene_desc;
 
+#define RTAMD_PRIMARY_RAYS_AUTO 0 /* per-pass screen binning of the faces (all primary rays share the eye) */
+#define RTAMD_PRIMARY_RAYS_TREE 1 /* primary rays walk the BVH like bounce rays                            */
 #define RTAMD_SHADOW_RAYS_AUTO 0 /* per-sample candidate grids when every sample direction allows it   */
 #define RTAMD_SHADOW_RAYS_TREE 1 /* shadow rays walk the BVH like every other ray                       */
 
@@ -91,7 +93,8 @@ typedef struct {
     int32_t max_leaf_faces; /* 1..15; 0 = default (4)                                              */
     int32_t sah_bins;       /* 4..64; 0 = default (16)                                             */
     int32_t shadow_rays;    /* RTAMD_SHADOW_RAYS_*                                                 */
-    int32_t reserved[5];
+    int32_t primary_rays;   /* RTAMD_PRIMARY_RAYS_*                                                */
+    int32_t reserved[4];
 } rtamd_build_params;
 
 /* What tracePixels/screenToWorld read from Tucano::Camera (camera.hpp:84,118-121,158-181). */

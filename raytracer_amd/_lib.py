@@ -11,6 +11,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_LIMIT, ERR_NO_DEVICE = 0, 1, 2, 3, 4
 FACE_SPHERE, FACE_MISS = -1, -2
 FLAG_COUNT_WORK, FLAG_TIME_KERNELS, FLAG_SINGLE_STREAM = 1, 2, 4
 SHADOW_RAYS_AUTO, SHADOW_RAYS_TREE = 0, 1
+PRIMARY_RAYS_AUTO, PRIMARY_RAYS_TREE = 0, 1
 
 
 class Material(C.Structure):
@@ -42,7 +43,8 @@ class SceneDesc(C.Structure):
 
 
 class BuildParams(C.Structure):
-    _fields_ = [("max_leaf_faces", C.c_int32), ("sah_bins", C.c_int32), ("shadow_rays", C.c_int32), ("reserved", C.c_int32 * 5)]
+    _fields_ = [("max_leaf_faces", C.c_int32), ("sah_bins", C.c_int32), ("shadow_rays", C.c_int32), ("primary_rays", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
 
 
 class Camera(C.Structure):

@@ -69,7 +69,9 @@ struct rtamd_scene {
     DeviceScene ds{};
     Workspace ws{};
     void *ws_block = nullptr;
+    size_t ws_bins = 0; // screen bins the workspace holds
     rtamd_scene_info info{};
+    bool bin_primary = true; // screen binning of the primary rays (rtamd_build_params::primary_rays)
     std::vector<rtamd_material> materials;
     std::vector<int32_t> face_material;
     // staging for the host-buffer entry point
@@ -101,8 +103,8 @@ int upload(void **dst, const std::vector<T> &src, uint64_t *bytes) {
 }
 
 // `slots` = ray slots of the local image = whole 8x8 tiles (a multiple of 64).
-int ensure_workspace(rtamd_scene *s, size_t slots) {
-    if (s->ws_block && (size_t)s->ws.capacity >= slots) return RTAMD_OK;
+int ensure_workspace(rtamd_scene *s, size_t slots, size_t bins_needed) {
+    if (s->ws_block && (size_t)s->ws.capacity >= slots && s->ws_bins >= (s->bin_primary ? bins_needed : 0)) return RTAMD_OK;
     if (s->ws_block) {
         HIP_TRY(hipFree(s->ws_block));
         s->ws_block = nullptr;
@@ -111,7 +113,12 @@ int ensure_workspace(rtamd_scene *s, size_t slots) {
     const size_t nshadow = (size_t)s->ds.num_lights * (size_t)s->ds.spl;
     const size_t planes = 2 /*slot tri, t*/ + 2 * 6 /*two hit lists: slot, tri, child, point*/ + 30 /*three queues*/;
     const size_t head = 4096; // stage counters + work counters
-    const size_t total = head + planes * cap * 4 + 2 * nshadow * cap;
+    // screen bins: sized for the whole image this workspace may see (the bins cover all rows, owned or not)
+    const size_t ntris = (size_t)s->info.num_device_faces;
+    const size_t bin_capacity = s->bin_primary ? std::min<size_t>(8 * ntris + (1u << 20), (size_t)1 << 30) : 0;
+    const size_t bins = s->bin_primary ? bins_needed : 0;
+    const size_t bin_bytes = s->bin_primary ? 256 + (2 * bins + 512 + bin_capacity) * 4 + (ntris + 1) * 16 : 0;
+    const size_t total = head + planes * cap * 4 + 2 * nshadow * cap + bin_bytes;
     HIP_TRY(hipMalloc(&s->ws_block, total));
     char *base = (char *)s->ws_block;
     s->ws.stage = (StageCounters *)base;
@@ -128,6 +135,17 @@ int ensure_workspace(rtamd_scene *s, size_t slots) {
     }
     for (float *&q : s->ws.queue) q = (float *)p, p += 10 * cap * 4;
     for (uint8_t *&c : s->ws.clear) c = (uint8_t *)p, p += nshadow * cap;
+    s->ws.bin_entries = nullptr;
+    if (s->bin_primary) {
+        p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
+        s->ws.big = (int4 *)p, p += (ntris + 1) * 16;
+        s->ws.bin_state = (BinState *)p, p += 256;
+        s->ws.bin_count = (int32_t *)p, p += (bins + 256) * 4;
+        s->ws.bin_start = (int32_t *)p, p += (bins + 256) * 4;
+        s->ws.bin_entries = (int32_t *)p, p += bin_capacity * 4;
+        s->ws.bin_capacity = (int32_t)bin_capacity;
+        s->ws_bins = bins;
+    }
     s->ws.capacity = (int32_t)cap;
     return RTAMD_OK;
 }
@@ -367,6 +385,7 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     s->ds.grid_cells = (const int32_t *)s->d_grid_cells;
     s->ds.grid_entries = (const int2 *)s->d_grid_entries;
     s->ds.use_grids = grids.usable ? 1 : 0;
+    s->bin_primary = !(build && build->primary_rays == RTAMD_PRIMARY_RAYS_TREE);
     s->info.shadow_grid_entries = grids.usable ? (uint64_t)grids.entries.size() : 0;
     s->ds.num_lights = d->num_lights;
     s->ds.spl = d->samples_per_light;
@@ -446,7 +465,8 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     const size_t nshadow = (size_t)s->ds.num_lights * (size_t)s->ds.spl;
     if (slots * (nshadow ? nshadow : 1) > (size_t)0x7f000000)
         return fail(RTAMD_ERR_LIMIT, "%zu ray slots x %zu shadow rays per hit exceed the 2^31 work-item limit of one launch", slots, nshadow);
-    rc = ensure_workspace(s, slots);
+    const int bins_x = (p->width + kBinPixels - 1) / kBinPixels, bins_y = (p->height + kBinPixels - 1) / kBinPixels;
+    rc = ensure_workspace(s, slots, (size_t)bins_x * (size_t)bins_y);
     if (rc != RTAMD_OK) return rc;
 
     FrameConst fc;
@@ -464,6 +484,30 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     fc.t_eps = p->t_epsilon, fc.refl_thresh = p->reflect_threshold, fc.bounce_off = p->bounce_offset;
     std::memcpy(fc.bg, p->background, sizeof fc.bg);
     std::memcpy(fc.bg_deep, p->background_deep, sizeof fc.bg_deep);
+
+    // inverse of camera_direction for the screen binning: r = s * L * (n + e), see project_point in kernels.hip
+    bool bins_ok = s->bin_primary && s->ws.bin_entries != nullptr && bins_x < 32768 && bins_y < 32768;
+    if (bins_ok) {
+        const float *m = cam->inv_view;
+        const double a = m[0], b = m[1], c = m[2], d0 = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+        const double c00 = e * i - f * h, c01 = f * g - d0 * i, c02 = d0 * h - e * g;
+        const double det = a * c00 + b * c01 + c * c02;
+        if (!(std::fabs(det) > 1e-30) || !std::isfinite(det)) {
+            bins_ok = false;
+        } else {
+            const double r = 1.0 / det;
+            const double inv[9] = {c00 * r, (c * h - b * i) * r, (b * f - c * e) * r, c01 * r, (a * i - c * g) * r,
+                                   (c * d0 - a * f) * r, c02 * r, (b * g - a * h) * r, (a * e - b * d0) * r};
+            const double dt[3] = {(double)m[3] - cam->origin[0], (double)m[7] - cam->origin[1], (double)m[11] - cam->origin[2]};
+            for (int k = 0; k < 9; ++k) fc.lin_inv[k] = (float)inv[k];
+            for (int k = 0; k < 3; ++k) fc.cam_e[k] = (float)(inv[3 * k] * dt[0] + inv[3 * k + 1] * dt[1] + inv[3 * k + 2] * dt[2]);
+            if (!(std::fabs(fc.cam_e[2] - 1.0f) > 1e-6f)) bins_ok = false;
+        }
+        fc.bins_x = bins_x, fc.bins_y = bins_y;
+    }
+    Workspace ws_frame = s->ws; // what the kernels of this frame see
+    if (!bins_ok) ws_frame.bin_entries = nullptr;
+    ws_frame.num_bins = bins_x * bins_y;
 
     const bool count = (p->flags & RTAMD_FLAG_COUNT_WORK) != 0;
     const bool timed = (p->flags & RTAMD_FLAG_TIME_KERNELS) != 0;
@@ -536,7 +580,8 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
                 // ---- closest hits
                 stream_of_launch = geo;
                 if ((rc = begin(0)) != RTAMD_OK) return rc;
-                launch_walk_closest(d == 0, count, s->ds, fc, s->ws, stage, d, geo);
+                if (d == 0 && bins_ok) launch_primary_bins(count, s->ds, fc, ws_frame, s->info.num_device_faces, geo);
+                launch_walk_closest(d == 0, count, s->ds, fc, ws_frame, stage, d, geo);
                 if ((rc = end()) != RTAMD_OK) return rc;
                 if (two_streams && d >= 2) HIP_TRY(hipStreamWaitEvent(geo, shaded(d - 2), 0));
                 if ((rc = begin(2)) != RTAMD_OK) return rc;

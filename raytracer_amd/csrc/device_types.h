@@ -44,6 +44,22 @@ struct FrameConst {
     float t_eps, refl_thresh, bounce_off;
     float bg[3], bg_deep[3];
     int32_t accumulate; // 0: first SSAA pass stores the pixel, 1: later passes add to it
+    // screen binning of the primary rays (raster_kernel): inverse of the linear part of inv_view, and that
+    // inverse applied to (inv_view translation - origin); bins of kBinPixels^2 pixels over the whole image
+    float lin_inv[9];
+    float cam_e[3];
+    int32_t bins_x, bins_y;
+};
+
+constexpr int kBinPixels = 4;   // screen bin edge; an 8x8 slot tile holds four bins
+constexpr int kBigBins = 256;   // a face covering more bins goes to the list every pixel scans
+
+// State of the per-pass screen binning, zeroed with the stage counters.
+struct BinState {
+    int32_t total;    // entries handed out so far (bin ranges are claimed block by block)
+    int32_t num_big;  // faces in the big list
+    int32_t fallback; // 1: the entry buffer is too small for this view -> the primary rays walk the tree
+    int32_t pad;
 };
 
 // Per-stage counters (one stage = one recursion level of one SSAA pass), zeroed once per frame.
@@ -81,6 +97,14 @@ struct Workspace {
     float *queue[3];
     StageCounters *stage; // kMaxStages
     WorkCounters *work;   // [0] closest-hit kernel, [1] shadow kernel
+    // screen binning of the primary rays; bin_entries == nullptr: not in use
+    BinState *bin_state;
+    int32_t *bin_count;   // per bin: faces whose projection touches it; then the fill cursor
+    int32_t *bin_start;   // per bin: first entry
+    int32_t *bin_entries; // TriRecord indices
+    int4 *big;            // (TriRecord index, first bin x | y << 16, last bin x | y << 16, 0)
+    int32_t bin_capacity; // entries
+    int32_t num_bins;
 };
 
 } // namespace rtamd

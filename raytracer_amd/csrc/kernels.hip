@@ -216,6 +216,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
     int *const leafq = s_stack + kLdsStack * 64 + lane;
     constexpr int CAP = MODE == kShadow ? kLeafQueue : kLeafQueueClosest;
 
+    if (MODE == kPrimary && ws.bin_entries && !ws.bin_state->fallback) return; // raster_kernel has done this pass
     const int nshadow = sc.num_lights * sc.spl;
     int rays, nhits = 0;
     if (MODE == kPrimary) {
@@ -443,6 +444,218 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
 }
 
 // ---------------------------------------------------------------------------------------------
+// Primary rays by screen binning.  All primary rays leave one point, so the faces a pixel's ray can hit are
+// those whose perspective projection covers the pixel.  Per pass: every face is projected, its pixel bounding
+// box (widened far beyond the rounding of the projection and of the exact test) is entered into the bins
+// of kBinPixels^2 pixels it touches (count, claim ranges, fill); then each pixel runs the exact plane +
+// three-edge test over the list of its bin and keeps the nearest face under the reference's tie rule.  The
+// exact test decides, so the result is the one the tree walk gives.  Faces with a vertex at or behind the
+// eye plane, or covering more than kBigBins bins, go to a short list that every pixel scans with a box
+// check.  When the entry buffer would overflow the pass sets BinState::fallback and the tree walk runs.
+// ---------------------------------------------------------------------------------------------
+struct PixelBox {
+    int x0, y0, x1, y1; // bins, inclusive, clamped to the image
+    bool empty, big;
+};
+
+// pixel position of a world point: inverse of camera_direction.  false: the point is not in front of the eye.
+__device__ __forceinline__ bool project_point(const FrameConst &fc, V3 p, float &px, float &py) {
+    const V3 r = p - mk(fc.origin[0], fc.origin[1], fc.origin[2]);
+    const float *m = fc.lin_inv;
+    const float qx = m[0] * r.x + (m[1] * r.y + m[2] * r.z);
+    const float qy = m[3] * r.x + (m[4] * r.y + m[5] * r.z);
+    const float qz = m[6] * r.x + (m[7] * r.y + m[8] * r.z);
+    // r = s * L * (n + e) with n.z = -1  ->  q = s * (n + e)
+    const float s = qz / (fc.cam_e[2] - 1.0f);
+    const float reach = fabsf(qx) + fabsf(qy) + fabsf(qz);
+    if (!(s > 1e-6f * reach)) return false;
+    const float nx = qx / s - fc.cam_e[0], ny = qy / s - fc.cam_e[1];
+    px = fc.vp[0] + (nx / fc.ax + 1.0f) * (0.5f * fc.vp[2]);
+    py = fc.vp[1] + (1.0f - ny / fc.scale) * (0.5f * fc.vp[3]);
+    return px == px && py == py;
+}
+
+__device__ __forceinline__ PixelBox face_bins(const DeviceScene &sc, const FrameConst &fc, int tri) {
+    PixelBox b;
+    b.empty = false, b.big = false;
+    const float4 p0 = sc.tris[tri * 4 + 1], p1 = sc.tris[tri * 4 + 2], p2 = sc.tris[tri * 4 + 3];
+    float x0 = 0, y0 = 0, x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+    const bool ok0 = project_point(fc, mk(p0.x, p0.y, p0.z), x0, y0);
+    const bool ok1 = project_point(fc, mk(p1.x, p1.y, p1.z), x1, y1);
+    const bool ok2 = project_point(fc, mk(p2.x, p2.y, p2.z), x2, y2);
+    const bool ok = ok0 && ok1 && ok2;
+    float xlo = 0.0f, ylo = 0.0f, xhi = (float)fc.width, yhi = (float)fc.height;
+    if (ok) {
+        // pixel (x, y) samples at (x + sub_x, y + sub_y): shift the box instead of the samples; the margin covers
+        // the rounding of the projection (about 1e-3 pixel at 8K) and of the exact test many times over
+        const float margin = 0.25f;
+        xlo = fminf(fminf(x0, x1), x2) - margin - fc.sub_x, xhi = fmaxf(fmaxf(x0, x1), x2) + margin - fc.sub_x;
+        ylo = fminf(fminf(y0, y1), y2) - margin - fc.sub_y, yhi = fmaxf(fmaxf(y0, y1), y2) + margin - fc.sub_y;
+    } else {
+        b.big = true; // a vertex beside or behind the eye: its projection is unbounded
+    }
+    // integer pixels inside [lo, hi]
+    const float fx0 = fmaxf(ceilf(xlo), 0.0f), fy0 = fmaxf(ceilf(ylo), 0.0f);
+    const float fx1 = fminf(floorf(xhi), (float)(fc.width - 1)), fy1 = fminf(floorf(yhi), (float)(fc.height - 1));
+    if (!(fx0 <= fx1 && fy0 <= fy1)) {
+        b.empty = true;
+        b.x0 = b.y0 = 0, b.x1 = b.y1 = -1;
+        return b;
+    }
+    b.x0 = (int)fx0 / kBinPixels, b.x1 = (int)fx1 / kBinPixels, b.y0 = (int)fy0 / kBinPixels, b.y1 = (int)fy1 / kBinPixels;
+    if ((b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1) > kBigBins) b.big = true;
+    return b;
+}
+
+// does this rank render any row of bin row `by`?  (row tiles are dealt round-robin, see global_row)
+__device__ __forceinline__ bool bin_row_owned(const FrameConst &fc, int by) {
+    if (fc.num_parts == 1) return true;
+    const int r0 = by * kBinPixels, r1 = min(r0 + kBinPixels - 1, fc.height - 1);
+    for (int t = r0 / fc.row_tile; t <= r1 / fc.row_tile; ++t)
+        if (t % fc.num_parts == fc.part) return true;
+    return false;
+}
+
+__global__ __launch_bounds__(256) void bin_count_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int num_tris) {
+    const int tri = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (tri >= num_tris) return;
+    const PixelBox b = face_bins(sc, fc, tri);
+    if (b.empty) return;
+    if (b.big) {
+        const int at = atomicAdd(&ws.bin_state->num_big, 1);
+        ws.big[at] = make_int4(tri, b.x0 | (b.y0 << 16), b.x1 | (b.y1 << 16), 0);
+        return;
+    }
+    for (int y = b.y0; y <= b.y1; ++y) {
+        if (!bin_row_owned(fc, y)) continue;
+        for (int x = b.x0; x <= b.x1; ++x) atomicAdd(&ws.bin_count[y * fc.bins_x + x], 1);
+    }
+}
+
+// Claims a contiguous range of the entry buffer for every bin: prefix sum inside a workgroup, one atomic per
+// workgroup.  Leaves bin_count = 0 for the fill pass to count up again.
+__global__ __launch_bounds__(256) void bin_offsets_kernel(Workspace ws) {
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const int bin = (int)(blockIdx.x * 256 + threadIdx.x);
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int c = bin < ws.num_bins ? ws.bin_count[bin] : 0;
+    // inclusive scan over the wave
+    int incl = c;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int n = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        int base = n ? atomicAdd(&ws.bin_state->total, n) : 0;
+        if (base + n > ws.bin_capacity) {
+            ws.bin_state->fallback = 1;
+            base = 0;
+        }
+        s_base = base;
+    }
+    __syncthreads();
+    int start = s_base + incl - c;
+    for (int w = 0; w < wave; ++w) start += s_wave[w];
+    if (bin < ws.num_bins) {
+        ws.bin_start[bin] = start;
+        ws.bin_count[bin] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void bin_fill_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int num_tris) {
+    const int tri = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (tri >= num_tris || ws.bin_state->fallback) return;
+    const PixelBox b = face_bins(sc, fc, tri);
+    if (b.empty || b.big) return;
+    for (int y = b.y0; y <= b.y1; ++y) {
+        if (!bin_row_owned(fc, y)) continue;
+        for (int x = b.x0; x <= b.x1; ++x) {
+            const int bin = y * fc.bins_x + x;
+            ws.bin_entries[ws.bin_start[bin] + atomicAdd(&ws.bin_count[bin], 1)] = tri;
+        }
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int total_static) {
+    if (ws.bin_state->fallback) return;
+    const int slot = (int)(blockIdx.x * 256 + threadIdx.x);
+    unsigned w_box = 0, w_plane = 0, w_edge = 0;
+    if (slot < total_static) {
+        int x, row;
+        if (!slot_pixel(fc, slot, x, row)) {
+            ws.slot_tri[slot] = -2; // padding of an edge tile
+        } else {
+            const int gy = global_row(fc, row);
+            const V3 o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
+            const V3 d = primary_direction(fc, x, row);
+            float tbest = FLT_MAX;
+            int best_tri = -2, best_rank = -1;
+            // intersects(): spheres first, then triangles, sharing the running maximum (:673-676)
+            if (sc.num_spheres > 0 && spheres_hit(sc, o, d, fc.t_eps, tbest)) best_tri = -1;
+            const int bx = x / kBinPixels, by = gy / kBinPixels;
+            const int bin = by * fc.bins_x + bx;
+            const int begin = ws.bin_start[bin], nlist = ws.bin_count[bin], nbig = ws.bin_state->num_big;
+            if (COUNT) ++w_box;
+            // Candidates are taken four at a time: the four index loads, then the four plane loads, are independent,
+            // so a long list costs a quarter of the dependent-load round trips.  The order of the candidates does
+            // not matter: equal distances are settled by the faces' ranks.
+            for (int e = 0; e < nlist + nbig; e += 4) {
+                int idx[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int ek = e + k;
+                    int i = -1;
+                    if (ek < nlist) {
+                        i = ws.bin_entries[begin + ek];
+                    } else if (ek < nlist + nbig) {
+                        const int4 g = ws.big[ek - nlist];
+                        if (!(bx < (g.y & 0xffff) || bx > (g.z & 0xffff) || by < (g.y >> 16) || by > (g.z >> 16))) i = g.x;
+                    }
+                    idx[k] = i;
+                }
+                // whole records up front: the edge tests then need no further round trip (lanes of one bin read the
+                // same records, so the extra loads are L1 hits)
+                float4 pn[4], q0[4], q1[4], q2[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 *rec = sc.tris + (size_t)max(idx[k], 0) * 4;
+                    pn[k] = rec[0], q0[k] = rec[1], q1[k] = rec[2], q2[k] = rec[3];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = idx[k];
+                    if (i < 0) continue;
+                    // exact plane + three-edge test, src/flyscene.cpp:752-789
+                    if (COUNT) ++w_plane;
+                    const V3 n = mk(pn[k].x, pn[k].y, pn[k].z);
+                    const float t = (pn[k].w - dot(o, n)) / dot(d, n);
+                    if (!(t >= fc.t_eps && t <= tbest)) continue; // also rejects NaN (see file header)
+                    const int rank = __float_as_int(q1[k].w);
+                    if (t == tbest && rank < best_rank) continue; // equal distance: the later face wins (:760)
+                    if (COUNT) ++w_edge;
+                    const V3 v0 = mk(q0[k].x, q0[k].y, q0[k].z), v1 = mk(q1[k].x, q1[k].y, q1[k].z), v2 = mk(q2[k].x, q2[k].y, q2[k].z);
+                    const V3 hp = o + t * d;
+                    if (dot(cross(v1 - v0, hp - v0), n) < 0) continue;
+                    if (dot(cross(v2 - v1, hp - v1), n) < 0) continue;
+                    if (dot(cross(v0 - v2, hp - v2), n) < 0) continue;
+                    tbest = t;
+                    best_tri = i;
+                    best_rank = rank;
+                }
+            }
+            ws.slot_tri[slot] = best_tri;
+            ws.slot_t[slot] = tbest;
+        }
+    }
+    if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Shadow rays through the candidate grids (shadow_grid.hpp).  All shadow rays of one light sample are
 // parallel (their direction is the sample's position, src/flyscene.cpp:884), so the faces that can occlude a
 // point are found by projecting the point along that direction into a 2D grid built once per scene.  One wave
@@ -483,26 +696,39 @@ __global__ __launch_bounds__(64) void shadow_grid_kernel(DeviceScene sc, FrameCo
             if (fx >= 0.0f && fy >= 0.0f && fx < (float)res && fy < (float)res) {
                 const int cell = first_cell + (int)fy * res + (int)fx;
                 const int begin = sc.grid_cells[cell], end = sc.grid_cells[cell + 1];
-                for (int e = begin; e < end; ++e) {
-                    const int2 ent = sc.grid_entries[e];
-                    if (__int_as_float(ent.y) < z) break; // this face and all later ones lie behind the origin
-                    const int i = ent.x;
-                    const float4 pn = sc.tris[i * 4 + 0];
-                    if (COUNT) ++w_plane;
-                    const V3 n = mk(pn.x, pn.y, pn.z);
-                    const float t = (pn.w - dot(o, n)) / dot(d, n);
-                    if (!(t >= fc.t_eps && t <= tbest)) continue; // also rejects NaN (see file header)
-                    const float4 p0 = sc.tris[i * 4 + 1];
-                    const float4 p1 = sc.tris[i * 4 + 2];
-                    const float4 p2 = sc.tris[i * 4 + 3];
-                    if (COUNT) ++w_edge;
-                    const V3 v0 = mk(p0.x, p0.y, p0.z), v1 = mk(p1.x, p1.y, p1.z), v2 = mk(p2.x, p2.y, p2.z);
-                    const V3 at = o + t * d;
-                    if (dot(cross(v1 - v0, at - v0), n) < 0) continue;
-                    if (dot(cross(v2 - v1, at - v1), n) < 0) continue;
-                    if (dot(cross(v0 - v2, at - v2), n) < 0) continue;
-                    blocked = true;
-                    break;
+                // four candidates at a time: independent entry loads, then independent plane loads
+                for (int e = begin; e < end && !blocked; e += 4) {
+                    int2 ent[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ent[k] = sc.grid_entries[min(e + k, end - 1)];
+                    float4 pn[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pn[k] = sc.tris[ent[k].x * 4 + 0];
+                    bool behind = false;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (blocked || behind || e + k >= end) continue;
+                        if (__int_as_float(ent[k].y) < z) { // this face and all later ones lie behind the origin
+                            behind = true;
+                            continue;
+                        }
+                        const int i = ent[k].x;
+                        if (COUNT) ++w_plane;
+                        const V3 n = mk(pn[k].x, pn[k].y, pn[k].z);
+                        const float t = (pn[k].w - dot(o, n)) / dot(d, n);
+                        if (!(t >= fc.t_eps && t <= tbest)) continue; // also rejects NaN (see file header)
+                        const float4 p0 = sc.tris[i * 4 + 1];
+                        const float4 p1 = sc.tris[i * 4 + 2];
+                        const float4 p2 = sc.tris[i * 4 + 3];
+                        if (COUNT) ++w_edge;
+                        const V3 v0 = mk(p0.x, p0.y, p0.z), v1 = mk(p1.x, p1.y, p1.z), v2 = mk(p2.x, p2.y, p2.z);
+                        const V3 at = o + t * d;
+                        if (dot(cross(v1 - v0, at - v0), n) < 0) continue;
+                        if (dot(cross(v2 - v1, at - v1), n) < 0) continue;
+                        if (dot(cross(v0 - v2, at - v2), n) < 0) continue;
+                        blocked = true;
+                    }
+                    if (behind) break;
                 }
             }
         }
@@ -818,11 +1044,26 @@ int walk_grid(long long groups) {
 }
 } // namespace
 
+void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, hipStream_t stream) {
+    const int total_static = fc.tiles_x * fc.tiles_y * 64;
+    (void)hipMemsetAsync(ws.bin_count, 0, sizeof(int32_t) * (size_t)ws.num_bins, stream);
+    (void)hipMemsetAsync(ws.bin_state, 0, sizeof(BinState), stream);
+    if (num_tris > 0) bin_count_kernel<<<(num_tris + 255) / 256, 256, 0, stream>>>(sc, fc, ws, num_tris);
+    bin_offsets_kernel<<<(ws.num_bins + 255) / 256, 256, 0, stream>>>(ws);
+    if (num_tris > 0) bin_fill_kernel<<<(num_tris + 255) / 256, 256, 0, stream>>>(sc, fc, ws, num_tris);
+    if (count)
+        raster_kernel<true><<<(total_static + 255) / 256, 256, 0, stream>>>(sc, fc, ws, total_static);
+    else
+        raster_kernel<false><<<(total_static + 255) / 256, 256, 0, stream>>>(sc, fc, ws, total_static);
+}
+
 void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth,
                          hipStream_t stream) {
     const int total_static = fc.tiles_x * fc.tiles_y * 64;
     // bounce queues are at most as long as the slot count: that is the worst case the grid covers
-    const int blocks = walk_grid(primary ? fc.tiles_x * fc.tiles_y : ws.capacity / 64);
+    // With screen binning in use the primary walk is only the fall-back of a pass whose bins overflowed: a
+    // small grid (the kernel strides over the groups) keeps the usual early exit cheap.
+    const int blocks = primary && ws.bin_entries ? 2048 : walk_grid(primary ? fc.tiles_x * fc.tiles_y : ws.capacity / 64);
     if (primary) {
         if (count)
             walk_kernel<kPrimary, true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, total_static);

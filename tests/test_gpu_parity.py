@@ -109,6 +109,36 @@ def test_shadow_grids_and_tree_walk_agree(name):
     assert sa.rays_shadow > 0
 
 
+@pytest.mark.parametrize("name,view", [("NthTest", "default"), ("toy_on_plane", "default"), ("bunny", "default"), ("toy", "inside"),
+                                       ("reflect_test", "close"), ("textured_quad", "default")])
+def test_screen_bins_and_tree_walk_agree_for_primary_rays(name, view):
+    """Primary rays are resolved by binning the projected faces per pass; forcing them through the BVH must give
+    the same planes bit for bit -- also with faces beside and behind the eye, SSAA sub-samples, a row partition
+    and a camera that has been turned."""
+    kw = dict(model=scene_path(name), output="")
+    a = R.Flyscene(**kw).initialize(120, 88)
+    b = R.Flyscene(primary_rays=L.PRIMARY_RAYS_TREE, **kw).initialize(120, 88)
+    for f in (a, b):
+        if view == "inside":
+            f.camera_translate(0.0, 0.0, 38.0)  # steps of 0.05: the eye ends up inside the model's bounding box
+            f.camera_rotate(0.3, -0.7)
+        elif view == "close":
+            f.camera_translate(2.0, -1.0, 24.0)
+            f.camera_rotate(-0.2, 0.4)
+    for params in (dict(), dict(ssaa_level=2), dict(row_tile=8, num_parts=3, part=1)):
+        a.set_params(**params)
+        b.set_params(**params)
+        ra, rb = a.render(), b.render()
+        assert np.array_equal(ra["face_id"], rb["face_id"]), (name, view, params)
+        assert np.array_equal(ra["rgb"].view(np.uint32), rb["rgb"].view(np.uint32)), (name, view, params)
+        sa, sb = ra["stats"], rb["stats"]
+        assert (sa.rays_primary, sa.rays_shadow, sa.rays_bounce, sa.hits) == (sb.rays_primary, sb.rays_shadow, sb.rays_bounce, sb.hits)
+        a.set_params(ssaa_level=1, row_tile=16, num_parts=1, part=0)
+        b.set_params(ssaa_level=1, row_tile=16, num_parts=1, part=0)
+        if not params:
+            assert (ra["face_id"] >= 0).any()
+
+
 def test_degenerate_sample_direction_falls_back_to_the_tree():
     # a light at the origin gives a zero shadow-ray direction (its hard-shadow sample): no grid can be built for it
     fly, orc = make_pair("glass", width=48, height=48, lights=[(0.0, 0.0, 0.0)], soft_points=0)
