@@ -486,7 +486,10 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     std::memcpy(fc.bg_deep, p->background_deep, sizeof fc.bg_deep);
 
     // inverse of camera_direction for the screen binning: r = s * L * (n + e), see project_point in kernels.hip
-    bool bins_ok = s->bin_primary && s->ws.bin_entries != nullptr && bins_x < 32768 && bins_y < 32768;
+    // binning pays when the faces are few against the pixels this rank renders: its cost grows with the faces,
+    // the tree walk's with the pixels (a tiny image of a huge mesh, or one rank of many, walks the tree)
+    bool bins_ok = s->bin_primary && s->ws.bin_entries != nullptr && bins_x < 32768 && bins_y < 32768 &&
+                   4 * (size_t)s->info.num_device_faces <= pixels;
     if (bins_ok) {
         const float *m = cam->inv_view;
         const double a = m[0], b = m[1], c = m[2], d0 = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];

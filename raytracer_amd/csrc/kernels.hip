@@ -184,6 +184,16 @@ constexpr int kLeafQueue = RT_LEAF_QUEUE;                // parked leaves per la
 constexpr int kLeafQueueClosest = RT_LEAF_QUEUE_CLOSEST; // closest-hit walks: parking delays the pruning
 static_assert(kLeafQueueClosest >= 1 && kLeafQueueClosest <= kLeafQueue, "leaf queue sizes");
 constexpr int kMinGroupShift = RT_MIN_GROUP_SHIFT; // narrowest group: 16 rays
+#ifndef RT_SPLIT_RAYS_BELOW
+#define RT_SPLIT_RAYS_BELOW (1 << 18)
+#endif
+#ifndef RT_SHADOW_SPLIT_BELOW
+#define RT_SHADOW_SPLIT_BELOW (1 << 16)
+#endif
+#ifndef RT_SHADOW_SPLIT_SHIFT
+#define RT_SHADOW_SPLIT_SHIFT 4
+#endif
+constexpr int kSplitRaysBelow = RT_SPLIT_RAYS_BELOW;           // bounce launches below this many rays put sixteen lanes on a ray
 constexpr int kFullChipWaves = 8192;               // a launch with fewer groups leaves SIMDs of the 256 CUs idle
 
 // Entry `sp` of the traversal stack.  The empty asm keeps the two loads in separate blocks: merged into one
@@ -232,13 +242,20 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
     int shift = 6;
     if (MODE == kQueue) // measured: no gain for shadow rays, whose groups already share origin region and direction
         while (shift > kMinGroupShift && (rays >> shift) < kFullChipWaves) --shift;
-    const int width = 1 << shift;
+    // Bounce launches smaller still are bound by their single slowest ray (a ray skimming a surface meets a
+    // hundred nodes and as many faces, one dependent fetch after the other).  Sixteen lanes then share one ray:
+    // each starts at one of the (up to) sixteen grandchildren of the root, the lanes prune against the nearest
+    // hit any of them has found so far, and the sixteen results are merged under the reference's tie rule.
+    const bool split = MODE == kQueue && rays < kSplitRaysBelow;
+    __shared__ int s_cut[4]; // per ray of the wave: bits of the nearest accepted distance
+    if (split) shift = 2;
+    const int width = split ? 64 : 1 << shift;
     const int per_sample = MODE == kShadow ? (nhits + width - 1) >> shift : 0; // hit chunks
-    const int ngroups = MODE == kShadow ? per_sample * nshadow : (rays + width - 1) >> shift;
+    const int ngroups = MODE == kShadow ? per_sample * nshadow : (rays + (1 << shift) - 1) >> shift;
     unsigned w_box = 0, w_plane = 0, w_edge = 0;
 
     for (int group = (int)blockIdx.x; group < ngroups; group += (int)gridDim.x) {
-        const int item = (group << shift) + lane;
+        const int item = split ? (group << 2) + (lane >> 4) : (group << shift) + lane;
 
         V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
         bool valid = lane < width;
@@ -302,8 +319,23 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
         if (ANY && best_tri == -1) node = kSentinel; // a sphere already blocks the sample
         // far limit, widened so that equal and last-bit-different distances are still visited
         float tlimit = ANY ? FLT_MAX : tbest * 1.000001f;
+        int *const cut_bits = s_cut + (lane >> 4);
+        if (split) {
+            const int sub = lane & 15, ci = sub >> 2, gk = sub & 3;
+            const int c = __float_as_int(((const float *)(sc.nodes + 6))[ci]); // child ci of the root
+            if (c >= 0)
+                node = __float_as_int(((const float *)(sc.nodes + (size_t)c * 8 + 6))[gk]);
+            else
+                node = gk == 0 ? c : kSentinel; // a leaf directly under the root goes to one lane
+            if (sub == 0) *cut_bits = __float_as_int(tbest);
+        }
 
         for (;;) {
+            float cut = FLT_MAX;
+            if (split) { // nearest hit of the ray so far, whichever lane found it (distances are >= 0: bits order)
+                cut = __int_as_float(*cut_bits);
+                tlimit = fminf(tlimit, cut * 1.000001f);
+            }
             // Node phase.  A leaf is parked in this lane's leaf queue and the descent goes on, so that the wave
             // switches between box tests and face tests as rarely as possible; a lane whose queue is full
             // waits for the others with the leaf still in `node`.
@@ -408,7 +440,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
                 if (COUNT) ++w_plane;
                 const V3 n = mk(pn.x, pn.y, pn.z);
                 const float t = (pn.w - dot(o, n)) / dot(d, n);
-                if (!(t >= fc.t_eps && t <= tbest)) continue; // also rejects NaN (see file header)
+                if (!(t >= fc.t_eps && t <= fminf(tbest, cut))) continue; // also rejects NaN (see file header)
                 const int rank = __float_as_int(p1.w);
                 if (!ANY && t == tbest && rank < best_rank) continue; // equal distance: the later face wins (:760)
                 if (COUNT) ++w_edge;
@@ -425,6 +457,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
                 best_tri = i;
                 best_rank = rank;
                 tlimit = t * 1.000001f;
+                if (split) atomicMin(cut_bits, __float_as_int(t));
             }
             nq = 0;
             if (ANY && blocked) {
@@ -433,6 +466,14 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
             }
         }
 
+        if (split) { // merge the sixteen lanes of the ray: nearest wins, equal distances go to the later face (:760)
+            for (int m = 1; m < 16; m <<= 1) {
+                const float ot = __shfl_xor(tbest, m, 64);
+                const int orank = __shfl_xor(best_rank, m, 64), otri = __shfl_xor(best_tri, m, 64);
+                if (ot < tbest || (ot == tbest && orank > best_rank)) tbest = ot, best_rank = orank, best_tri = otri;
+            }
+            if ((lane & 15) != 0) continue;
+        }
         if (ANY) {
             ws.clear[depth & 1][out_index] = best_tri == -2 ? 1 : 0;
         } else {
@@ -669,21 +710,29 @@ __global__ __launch_bounds__(64) void shadow_grid_kernel(DeviceScene sc, FrameCo
     const int lane = (int)threadIdx.x;
     const int nshadow = sc.num_lights * sc.spl;
     const int nhits = ws.stage[stage].hits;
-    const int chunks = (nhits + 63) >> 6;
+    // Lanes per ray.  A launch too small to fill the chip (the shadow rays of bounce hits) is bound by the ray
+    // with the longest candidate list; sixteen lanes then share one ray, each taking every sixteenth batch of
+    // its list, and combine their verdicts at the end.
+    const long long rays = (long long)nhits * nshadow;
+    const int split_shift = rays < RT_SHADOW_SPLIT_BELOW ? RT_SHADOW_SPLIT_SHIFT : 0;
+    const int split = 1 << split_shift, per_wave_shift = 6 - split_shift;
+    const int sub = lane & (split - 1);
+    const int chunks = (nhits + (1 << per_wave_shift) - 1) >> per_wave_shift;
     const int ngroups = chunks * nshadow;
     unsigned w_box = 0, w_plane = 0, w_edge = 0;
     for (int group = (int)blockIdx.x; group < ngroups; group += (int)gridDim.x) {
         const int chunk = group / nshadow, sample = group - chunk * nshadow;
-        const int hit = (chunk << 6) + lane;
-        if (hit >= nhits) continue;
+        const int hit = (chunk << per_wave_shift) + (lane >> split_shift);
+        const bool valid = hit < nhits;
         const float *hp = ws.hits[depth & 1].p;
-        const V3 o = mk(hp[hit], hp[(size_t)ws.capacity + hit], hp[2 * (size_t)ws.capacity + hit]);
+        const int hit_c = valid ? hit : 0; // lanes past the end stay in step for the cross-lane vote below
+        const V3 o = mk(hp[hit_c], hp[(size_t)ws.capacity + hit_c], hp[2 * (size_t)ws.capacity + hit_c]);
         const V3 d = mk(sc.samples[3 * sample], sc.samples[3 * sample + 1], sc.samples[3 * sample + 2]);
         bool blocked = false;
         // intersects(): spheres first (:673-676)
         float tbest = FLT_MAX;
         if (sc.num_spheres > 0 && spheres_hit(sc, o, d, fc.t_eps, tbest)) blocked = true;
-        if (!blocked) {
+        if (!blocked && valid) {
             const float4 g0 = sc.grid_headers[sample * 4 + 0], g1 = sc.grid_headers[sample * 4 + 1];
             const float4 g2 = sc.grid_headers[sample * 4 + 2], g3 = sc.grid_headers[sample * 4 + 3];
             // header: U (g0.xyz), V (g0.w g1.xy), W (g1.zw g2.x), u0 v0 inv_cell (g2.yzw), res first_cell (g3.xy)
@@ -692,12 +741,12 @@ __global__ __launch_bounds__(64) void shadow_grid_kernel(DeviceScene sc, FrameCo
             const float z = o.x * g1.z + (o.y * g1.w + o.z * g2.x);
             const float fx = floorf((u - g2.y) * g2.w), fy = floorf((v - g2.z) * g2.w);
             const int res = __float_as_int(g3.x), first_cell = __float_as_int(g3.y);
-            if (COUNT) ++w_box;
+            if (COUNT && sub == 0) ++w_box;
             if (fx >= 0.0f && fy >= 0.0f && fx < (float)res && fy < (float)res) {
                 const int cell = first_cell + (int)fy * res + (int)fx;
                 const int begin = sc.grid_cells[cell], end = sc.grid_cells[cell + 1];
                 // four candidates at a time: independent entry loads, then independent plane loads
-                for (int e = begin; e < end && !blocked; e += 4) {
+                for (int e = begin + 4 * sub; e < end && !blocked; e += 4 * split) {
                     int2 ent[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) ent[k] = sc.grid_entries[min(e + k, end - 1)];
@@ -732,7 +781,10 @@ __global__ __launch_bounds__(64) void shadow_grid_kernel(DeviceScene sc, FrameCo
                 }
             }
         }
-        ws.clear[depth & 1][sample * ws.capacity + hit] = blocked ? 0 : 1;
+        // any lane of the ray's group found an occluder?  (every lane of the wave reaches this point)
+        int any = blocked ? 1 : 0;
+        for (int m = 1; m < split; m <<= 1) any |= __shfl_xor(any, m, 64);
+        if (valid && sub == 0) ws.clear[depth & 1][sample * ws.capacity + hit] = any ? 0 : 1;
     }
     if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 1);
 }
