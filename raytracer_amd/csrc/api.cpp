@@ -1,8 +1,9 @@
 // C ABI of the render pass (include/rtamd.h): scene upload, frame orchestration, statistics.
 //
-// A frame is a fixed sequence of launches on one stream with no host round trip:
-//   memset(counters); for each SSAA pass, for depth 0..D: trace(depth), shade(depth); [scale]
-// which is the iterative form of Flyscene::traceRay's recursion (src/flyscene.cpp:581-667): the
+// A frame is a fixed sequence of launches with no host round trip:
+//   memset(counters); for each SSAA pass, for depth 0..D: closest hits, compact, shadow rays, shade; [scale]
+// (on the caller's stream; with reflections the deeper stages overlap on two side streams, see
+// rtamd_render_device), which is the iterative form of Flyscene::traceRay's recursion (src/flyscene.cpp:581-667): the
 // colour C = local + ks*LI*C_next is accumulated front to back with a running throughput.
 #include <hip/hip_runtime.h>
 

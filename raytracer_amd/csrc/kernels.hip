@@ -1,24 +1,36 @@
 // gfx950 kernels of the Flyscene render pass.
 //
-// One recursion level of Flyscene::traceRay (src/flyscene.cpp:581-667) is four launches:
+// One recursion level of Flyscene::traceRay (src/flyscene.cpp:581-667) is: closest hits, compaction,
+// shadow rays, shading.
 //
-//   walk_kernel<CLOSEST>  closest hit of every ray of the level: intersects() = sphereIntersection +
-//                         triangleIntersection (src/flyscene.cpp:669-793), with boundingBox::
-//                         intersectingBoxes (src/boundingBox.h:295-307) replaced by an ordered,
-//                         distance-pruned walk of the flat BVH.  Level 0 generates the camera rays
-//                         (tracePixels, src/flyscene.cpp:808-822; Camera::screenToWorld, camera.hpp:158-176).
-//   compact_kernel        gathers the rays that hit something into a dense list (hit point included).
-//   walk_kernel<SHADOW>   the shadow rays of getLightIntensity (src/flyscene.cpp:870-896), one ray per
-//                         (hit, light sample), as any-hit queries.
-//   shade_kernel          shadeOffFace (:461-579) per hit and the reflection set-up of traceRay
-//                         (:617-646), which fills the ray queue of the next level.
+//   closest hits   intersects() = sphereIntersection + triangleIntersection (src/flyscene.cpp:669-793).
+//                  Level 0 (tracePixels, src/flyscene.cpp:808-822; Camera::screenToWorld, camera.hpp:158-176):
+//                  all rays leave the eye, so the faces are binned on the screen once per pass
+//                  (bin_count / bin_offsets / bin_fill) and raster_kernel tests the bin of each pixel.
+//                  Deeper levels, and level 0 when binning does not pay: walk_kernel, an ordered,
+//                  distance-pruned walk of a four-way BVH standing in for boundingBox::intersectingBoxes
+//                  (src/boundingBox.h:295-307).
+//   compact_kernel gathers the rays that hit something into a dense list (hit point included) and sets
+//                  up the reflection rays of traceRay (:617-646) in the queue of the next level.
+//   shadow rays    getLightIntensity (src/flyscene.cpp:870-896), one any-hit ray per (hit, light sample).
+//                  The direction of such a ray is the sample's position (:884), the same for every hit:
+//                  shadow_grid_kernel looks the hit up in a per-sample 2D grid of the faces, built once per
+//                  scene.  walk_kernel<kShadow> is the fall-back.
+//   shade_kernel   shadeOffFace (:461-579) per hit, accumulation into the pixel, throughput of the
+//                  reflection ray.
+//
+// Every candidate structure above (bins, grids, tree) is conservative and only proposes faces; a face is
+// accepted by the reference's plane + three-edge arithmetic alone, and equal distances are settled by the
+// faces' ranks in the reference's visiting order, so the outcome does not depend on which structure or
+// which order proposed the face.
 //
 // Arithmetic contract: this file is compiled with -ffp-contract=off and without fast-math.  Every
 // expression that decides a hit, a distance, a hit point or a shadow is written in the reference's
 // evaluation order (Eigen's 3-vector reductions associate as x + (y + z)), so those values are
-// bit-identical to a strict binary32 evaluation of the reference.  The slab tests are the only
-// place where explicit fused multiply-adds and a reciprocal are used; they are conservative
-// (the exit distance is widened), and a widened test can only add faces to be tested exactly.
+// bit-identical to a strict binary32 evaluation of the reference.  The slab tests, the screen projection
+// and the grid projection are the only places with explicit fused multiply-adds, reciprocals or free
+// evaluation order; they are conservative (intervals and boxes are widened far beyond their rounding), and
+// a widened candidate test can only add faces to be tested exactly.
 // Deliberate deviation: a NaN plane distance (ray inside a face plane, 0/0) is rejected, whereas
 // the reference accepts it and then returns a visiting-order-dependent face.
 #include <hip/hip_runtime.h>
