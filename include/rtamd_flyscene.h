@@ -22,7 +22,10 @@ int rtfly_destroy(rtfly *f);
 
 /* Scene inputs; call before rtfly_initialize.  The reference hard-codes all of them
  * (src/flyscene.cpp:8-16,39; src/flyscene.hpp:22-41). */
-int rtfly_set_model(rtfly *f, const char *obj_path);     /* default "resources/models/bunny.obj"   */
+int rtfly_set_model(rtfly *f, const char *obj_path);     /* default "resources/models/bunny.obj"; a name ending
+                                                            in ".ply" is read as PLY (ascii or binary
+                                                            little-endian, triangles), which the reference
+                                                            only previews (utils/plyimporter.hpp:213-284) */
 /* Mesh given as arrays instead of an OBJ file (file coordinates; normals may be NULL; one material
  * id per face, -1 = none).  Same derived quantities as the OBJ path. */
 int rtfly_set_model_arrays(rtfly *f, const float *vertices, const float *normals, int32_t num_vertices,
@@ -76,6 +79,9 @@ int rtfly_get_array(rtfly *f, const char *name, const void **data, int64_t *coun
 
 /* ImageImporter::writePPMImage, utils/ppmIO.hpp:188-209. */
 int rtfly_write_ppm(const char *path, const float *rgb, int32_t width, int32_t height);
+/* Same quantisation (utils/ppmIO.hpp:203), written as binary P6.  rtfly_set_output with a name ending in
+ * ".p6.ppm" or ".pnm" makes rtfly_raytrace_scene write this form. */
+int rtfly_write_ppm_binary(const char *path, const float *rgb, int32_t width, int32_t height);
 
 #ifdef __cplusplus
 }

@@ -136,6 +136,7 @@ SYMBOLS = {
     "rtfly_scene": (_P, [_P]),
     "rtfly_get_array": (C.c_int, [_P, C.c_char_p, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "rtfly_write_ppm": (C.c_int, [C.c_char_p, _fp, C.c_int32, C.c_int32]),
+    "rtfly_write_ppm_binary": (C.c_int, [C.c_char_p, _fp, C.c_int32, C.c_int32]),
 }
 
 _lib = None

@@ -315,6 +315,195 @@ bool load_obj(const std::string &path, HostMesh &mesh, std::string &error) {
     return load_material_textures(mesh, error);
 }
 
+namespace {
+struct PlyProp {
+    std::string name;
+    int bytes;      // size of the scalar, or of one list item
+    int count_bytes; // > 0: a list, size of its count field
+    char kind;      // 'f' float32, 'd' float64, 'i' signed, 'u' unsigned
+};
+bool ply_type(const std::string &t, int &bytes, char &kind) {
+    if (t == "float" || t == "float32") return bytes = 4, kind = 'f', true;
+    if (t == "double" || t == "float64") return bytes = 8, kind = 'd', true;
+    if (t == "char" || t == "int8") return bytes = 1, kind = 'i', true;
+    if (t == "uchar" || t == "uint8") return bytes = 1, kind = 'u', true;
+    if (t == "short" || t == "int16") return bytes = 2, kind = 'i', true;
+    if (t == "ushort" || t == "uint16") return bytes = 2, kind = 'u', true;
+    if (t == "int" || t == "int32") return bytes = 4, kind = 'i', true;
+    if (t == "uint" || t == "uint32") return bytes = 4, kind = 'u', true;
+    return false;
+}
+double ply_scalar(const unsigned char *p, int bytes, char kind) {
+    switch (kind) {
+    case 'f': { float v; std::memcpy(&v, p, 4); return v; }
+    case 'd': { double v; std::memcpy(&v, p, 8); return v; }
+    case 'i':
+        if (bytes == 1) return (signed char)p[0];
+        if (bytes == 2) { int16_t v; std::memcpy(&v, p, 2); return v; }
+        { int32_t v; std::memcpy(&v, p, 4); return v; }
+    default:
+        if (bytes == 1) return p[0];
+        if (bytes == 2) { uint16_t v; std::memcpy(&v, p, 2); return v; }
+        { uint32_t v; std::memcpy(&v, p, 4); return v; }
+    }
+}
+} // namespace
+
+bool load_ply(const std::string &path, HostMesh &mesh, std::string &error) {
+    std::ifstream in(path.c_str(), std::ios::binary);
+    if (!in) {
+        error = "Cannot open " + path;
+        return false;
+    }
+    mesh = HostMesh();
+    std::string line;
+    if (!std::getline(in, line) || line.compare(0, 3, "ply") != 0) {
+        error = "not a PLY file: " + path;
+        return false;
+    }
+    bool ascii = false, known_format = false;
+    struct Element {
+        std::string name;
+        long count;
+        std::vector<PlyProp> props;
+    };
+    std::vector<Element> elements;
+    while (std::getline(in, line)) {
+        erase_crlf(line);
+        std::istringstream ls(line);
+        std::string key;
+        ls >> key;
+        if (key == "end_header") break;
+        if (key == "format") {
+            std::string f;
+            ls >> f;
+            ascii = f == "ascii";
+            known_format = ascii || f == "binary_little_endian";
+        } else if (key == "element") {
+            Element e;
+            ls >> e.name >> e.count;
+            elements.push_back(e);
+        } else if (key == "property" && !elements.empty()) {
+            PlyProp p;
+            std::string t;
+            ls >> t;
+            p.count_bytes = 0;
+            bool ok = true;
+            if (t == "list") {
+                std::string ct, it;
+                ls >> ct >> it;
+                char ck;
+                ok = ply_type(ct, p.count_bytes, ck) && ply_type(it, p.bytes, p.kind);
+            } else {
+                ok = ply_type(t, p.bytes, p.kind);
+            }
+            ls >> p.name;
+            if (!ok) {
+                error = "unknown PLY property type in " + path + ": " + line;
+                return false;
+            }
+            elements.back().props.push_back(p);
+        }
+    }
+    if (!known_format) {
+        error = "PLY format must be ascii or binary_little_endian: " + path;
+        return false;
+    }
+    std::vector<float> file_normals;
+    auto read_value = [&](const PlyProp &p, bool count_field, double &out) -> bool {
+        const int bytes = count_field ? p.count_bytes : p.bytes;
+        const char kind = count_field ? 'u' : p.kind;
+        if (ascii) return (bool)(in >> out);
+        unsigned char buf[8];
+        if (!in.read((char *)buf, bytes)) return false;
+        out = ply_scalar(buf, bytes, kind);
+        return true;
+    };
+    for (const Element &e : elements) {
+        for (long i = 0; i < e.count; ++i) {
+            float xyz[3] = {0, 0, 0}, nrm[3] = {0, 0, 0};
+            bool have_n = false;
+            for (const PlyProp &p : e.props) {
+                if (p.count_bytes == 0) {
+                    double v;
+                    if (!read_value(p, false, v)) {
+                        error = "PLY file ends early: " + path;
+                        return false;
+                    }
+                    if (e.name == "vertex") {
+                        if (p.name == "x") xyz[0] = (float)v;
+                        if (p.name == "y") xyz[1] = (float)v;
+                        if (p.name == "z") xyz[2] = (float)v;
+                        if (p.name == "nx") nrm[0] = (float)v, have_n = true;
+                        if (p.name == "ny") nrm[1] = (float)v;
+                        if (p.name == "nz") nrm[2] = (float)v;
+                    }
+                } else {
+                    double cnt;
+                    if (!read_value(p, true, cnt) || cnt < 0 || cnt > 255) {
+                        error = "bad PLY list in " + path;
+                        return false;
+                    }
+                    std::vector<int32_t> ids;
+                    for (int k = 0; k < (int)cnt; ++k) {
+                        double v;
+                        if (!read_value(p, false, v)) {
+                            error = "PLY file ends early: " + path;
+                            return false;
+                        }
+                        ids.push_back((int32_t)v);
+                    }
+                    if (e.name == "face" && (p.name == "vertex_indices" || p.name == "vertex_index")) {
+                        if (ids.size() != 3) {
+                            error = "only triangle faces are supported in PLY files: " + path;
+                            return false;
+                        }
+                        mesh.face_vertex.insert(mesh.face_vertex.end(), ids.begin(), ids.end());
+                    }
+                }
+            }
+            if (e.name == "vertex") {
+                mesh.vertices.insert(mesh.vertices.end(), xyz, xyz + 3);
+                if (have_n) file_normals.insert(file_normals.end(), nrm, nrm + 3);
+            }
+        }
+    }
+    const int32_t nv = mesh.num_vertices();
+    for (int32_t id : mesh.face_vertex)
+        if (id < 0 || id >= nv) {
+            error = "face references vertex " + std::to_string(id) + " of " + std::to_string(nv) + " in " + path;
+            return false;
+        }
+    // materials: <name>.mtl beside the file, first material for every face
+    std::string mtl = path;
+    const size_t dot = mtl.find_last_of('.');
+    if (dot != std::string::npos) mtl = mtl.substr(0, dot);
+    mtl += ".mtl";
+    int32_t material = -1;
+    if (std::ifstream(mtl.c_str()).good() && load_mtl(mtl, mesh.materials)) material = 0;
+    mesh.face_material.assign((size_t)mesh.num_faces(), material);
+    const bool paired = (int32_t)(file_normals.size() / 3) == nv && nv > 0;
+    if (paired) mesh.normals = file_normals;
+    finish_mesh(mesh, paired);
+    return load_material_textures(mesh, error);
+}
+
+bool write_ppm_binary(const std::string &path, const float *rgb, int width, int height) {
+    std::FILE *out = std::fopen(path.c_str(), "wb");
+    if (!out) return false;
+    std::fprintf(out, "P6\n%d %d\n255\n", width, height);
+    std::vector<unsigned char> row((size_t)width * 3);
+    for (int j = 0; j < height; ++j) {
+        for (int i = 0; i < width * 3; ++i) {
+            const int v = std::min(255, (int)(255 * rgb[(size_t)j * width * 3 + i])); // ppmIO.hpp:203
+            row[(size_t)i] = (unsigned char)std::max(v, 0);
+        }
+        std::fwrite(row.data(), 1, row.size(), out);
+    }
+    std::fclose(out);
+    return true;
+}
+
 // utils/ppmIO.hpp:188-209: ASCII P3, each channel min(255, (int)(255 * c)), one text line per row.
 bool write_ppm(const std::string &path, const float *rgb, int width, int height) {
     std::FILE *out = std::fopen(path.c_str(), "w");
@@ -580,7 +769,9 @@ int Flyscene::initialize(int width, int height, bool do_upload) {
     flycamera.setViewport((float)width, (float)height);                                  // :36
     if (!mesh_from_arrays) {
         std::string err;
-        if (!load_obj(model_path, mesh, err)) {
+        const bool is_ply = model_path.size() >= 4 && (model_path.compare(model_path.size() - 4, 4, ".ply") == 0 ||
+                                                        model_path.compare(model_path.size() - 4, 4, ".PLY") == 0);
+        if (!(is_ply ? load_ply(model_path, mesh, err) : load_obj(model_path, mesh, err))) {
             std::fprintf(stderr, "%s\n", err.c_str());
             return RTAMD_ERR_INVALID;
         }
@@ -620,7 +811,14 @@ int Flyscene::raytraceScene() {
     const int rc = render(pixel_data.data(), nullptr, nullptr);
     params = saved;
     if (rc != RTAMD_OK) return rc;
-    if (!output_path.empty() && !write_ppm(output_path, pixel_data.data(), size[0], size[1])) return RTAMD_ERR_INVALID;
+    auto ends_with = [&](const char *suffix) {
+        const size_t n = std::strlen(suffix);
+        return output_path.size() >= n && output_path.compare(output_path.size() - n, n, suffix) == 0;
+    };
+    const bool binary = ends_with(".p6.ppm") || ends_with(".pnm");
+    if (!output_path.empty() &&
+        !(binary ? write_ppm_binary(output_path, pixel_data.data(), size[0], size[1]) : write_ppm(output_path, pixel_data.data(), size[0], size[1])))
+        return RTAMD_ERR_INVALID;
     return RTAMD_OK;
 }
 
@@ -802,6 +1000,11 @@ int rtfly_get_array(rtfly *f, const char *name, const void **data, int64_t *coun
         return set(&s.mesh.textures[k].width, 2);
     }
     return RTAMD_ERR_INVALID;
+}
+
+int rtfly_write_ppm_binary(const char *path, const float *rgb, int32_t w, int32_t h) {
+    if (!path || !rgb || w <= 0 || h <= 0) return RTAMD_ERR_INVALID;
+    return rtamd::write_ppm_binary(path, rgb, w, h) ? RTAMD_OK : RTAMD_ERR_INVALID;
 }
 
 int rtfly_write_ppm(const char *path, const float *rgb, int32_t w, int32_t h) {

@@ -45,11 +45,17 @@ struct HostMesh {
 };
 
 bool load_obj(const std::string &path, HostMesh &mesh, std::string &error);
+// Binary or ASCII PLY with float x y z [nx ny nz] (other vertex properties skipped) and triangle faces.  The
+// reference only previews PLY files (utils/plyimporter.hpp:213-284); here they feed the same pipeline as an
+// OBJ.  Materials: `<name>.mtl` beside the file if present (its first material for every face), else none.
+bool load_ply(const std::string &path, HostMesh &mesh, std::string &error);
 bool load_mtl(const std::string &path, std::vector<NamedMaterial> &materials);
 bool load_ppm_texture(const std::string &path, HostTexture &tex, std::string &error); // utils/ppmIO.hpp:36-86
 bool load_material_textures(HostMesh &mesh, std::string &error);                       // src/flyscene.cpp:52-71
 void finish_mesh(HostMesh &mesh, bool have_normals);
 bool write_ppm(const std::string &path, const float *rgb, int width, int height);
+// Same quantisation as write_ppm, written as binary P6 (a tenth of the bytes, no text formatting).
+bool write_ppm_binary(const std::string &path, const float *rgb, int width, int height);
 
 // Subset of Tucano::Flycamera / Tucano::Camera that the traced path touches.
 class Flycamera {

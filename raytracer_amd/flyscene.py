@@ -255,11 +255,14 @@ def texture_arrays(fly):
     return out
 
 
-def write_ppm(path, rgb):
-    """ImageImporter::writePPMImage (utils/ppmIO.hpp:188-209)."""
+def write_ppm(path, rgb, binary=False):
+    """ImageImporter::writePPMImage (utils/ppmIO.hpp:188-209); binary=True writes P6 with the same quantisation."""
     rgb = np.ascontiguousarray(rgb, np.float32)
     h, w, _ = rgb.shape
-    L.check(L.lib().rtfly_write_ppm(os.fsencode(path), _fptr(rgb), w, h), "rtfly_write_ppm")
+    if binary:
+        L.check(L.lib().rtfly_write_ppm_binary(os.fsencode(path), _fptr(rgb), w, h), "rtfly_write_ppm_binary")
+    else:
+        L.check(L.lib().rtfly_write_ppm(os.fsencode(path), _fptr(rgb), w, h), "rtfly_write_ppm")
 
 
 def default_camera(width, height):
