@@ -164,13 +164,15 @@ def main():
     base = fly.params_copy(row_tile=a.row_tile)
     mine = tiles.part_params(base, world, rank)
     rows = fly.local_rows(mine)
-    rgb = torch.zeros((max(rows, 1), W, 3), dtype=torch.float32, device=dev)
+    # padded to the largest row count of any rank, so that the gather needs no staging copy
+    rows_alloc = max(rows, 1) if world == 1 else max(tiles.layout(base, world)[1], 1)
+    rgb = torch.zeros((rows_alloc, W, 3), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
 
     def frame(p):
         fly.render_device(rgb, params=p, camera=cam, stream=stream)
         if world > 1:
-            return tiles.gather_rows(rgb[:rows], p, dst=0)
+            return tiles.gather_rows(rgb, p, dst=0)
         return rgb
 
     def sync():

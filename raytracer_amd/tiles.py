@@ -28,31 +28,54 @@ def local_rows(params, world, rank):
     return L.lib().rtamd_local_rows(C.byref(part_params(params, world, rank)))
 
 
-def row_permutation(params, world, device="cpu"):
-    """index[y] = row of the part-major concatenation (rank 0's rows, then rank 1's, ...) that holds
-    image row y."""
+_layout_cache = {}
+
+
+def layout(params, world):
+    """(rows of every rank, largest of them, index) for the partition `params` describes over `world` ranks;
+    index[y] = row of the part-major concatenation of PADDED blocks (rank r's rows start at r * rows_max)
+    that holds image row y.  Cached: a frame loop must not pay a Python loop over the image rows per frame."""
+    key = (params.height, params.row_tile, world)
+    hit = _layout_cache.get(key)
+    if hit is not None:
+        return hit
     lib = L.lib()
-    height = params.height
-    index = torch.empty(height, dtype=torch.long)
+    rows = []
+    index_padded = torch.empty(params.height, dtype=torch.long)
+    index_packed = torch.empty(params.height, dtype=torch.long)
+    for r in range(world):
+        p = part_params(params, world, r)
+        rows.append(lib.rtamd_local_rows(C.byref(p)))
+    rows_max = max(rows) if rows else 0
     base = 0
     for r in range(world):
         p = part_params(params, world, r)
-        n = lib.rtamd_local_rows(C.byref(p))
-        for lr in range(n):
-            index[lib.rtamd_global_row(C.byref(p), lr)] = base + lr
-        base += n
-    assert base == height, (base, height)
-    return index.to(device)
+        for lr in range(rows[r]):
+            y = lib.rtamd_global_row(C.byref(p), lr)
+            index_padded[y] = r * rows_max + lr
+            index_packed[y] = base + lr
+        base += rows[r]
+    assert base == params.height, (base, params.height)
+    out = (rows, rows_max, index_padded, index_packed, {})
+    _layout_cache[key] = out
+    return out
+
+
+def row_permutation(params, world, device="cpu"):
+    """index[y] = row of the part-major concatenation (rank 0's rows, then rank 1's, ...) that holds
+    image row y."""
+    return layout(params, world)[3].to(device)
 
 
 def gather_rows(local, params, group=None, dst=0):
-    """Gather every rank's packed rows (`local`: [rows, width, ch]) on `dst` and return the assembled
-    [height, width, ch] image there (None elsewhere).  One collective, no other traffic."""
+    """Gather every rank's packed rows (`local`: [rows, width, ch], or already padded to the largest row count
+    of any rank) on `dst` and return the assembled [height, width, ch] image there (None elsewhere).  One
+    collective, no other traffic; the root restores row order in one pass over the gathered buffer."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world == 1:
         return local[: params.height]
-    rows_max = max(local_rows(params, world, r) for r in range(world))
+    rows, rows_max, index_padded, _, on_device = layout(params, world)
     shape = (rows_max,) + tuple(local.shape[1:])
     send = local
     if local.shape[0] != rows_max:  # pad so that every rank contributes the same size
@@ -60,10 +83,13 @@ def gather_rows(local, params, group=None, dst=0):
         send[: local.shape[0]] = local
     send = send.contiguous()
     if rank == dst:
-        recv = [torch.empty(shape, dtype=local.dtype, device=local.device) for _ in range(world)]
-        dist.gather(send, recv, dst=dst, group=group)
-        parts = [recv[r][: local_rows(params, world, r)] for r in range(world)]
-        packed = torch.cat(parts, dim=0)
-        return packed.index_select(0, row_permutation(params, world, packed.device))
+        key = (str(local.device), local.dtype, shape)
+        cached = on_device.get(key)
+        if cached is None:
+            cached = (torch.empty((world,) + shape, dtype=local.dtype, device=local.device), index_padded.to(local.device))
+            on_device[key] = cached
+        recv_all, index = cached
+        dist.gather(send, list(recv_all.unbind(0)), dst=dst, group=group)
+        return recv_all.view((world * rows_max,) + tuple(local.shape[1:])).index_select(0, index)
     dist.gather(send, None, dst=dst, group=group)
     return None
