@@ -93,3 +93,67 @@ def gather_rows(local, params, group=None, dst=0):
         return recv_all.view((world * rows_max,) + tuple(local.shape[1:])).index_select(0, index)
     dist.gather(send, None, dst=dst, group=group)
     return None
+
+
+class GatherPipeline:
+    """Double-buffered frames for a render loop: frame k's gather runs (asynchronously, on the collective's own
+    stream) while frame k+1 is rendered into the other buffer.  Usage, every rank alike:
+
+        pipe = GatherPipeline(params, width, channels, device)
+        for k in range(frames):
+            buf = pipe.acquire()          # waits (on the stream, not the host) until the gather two frames back is done
+            render into buf[:local_rows]
+            image = pipe.submit()         # starts this frame's gather; returns the frame finished by acquire(), if any
+        last = pipe.drain()               # list of the frames still in flight, oldest first
+
+    Images are returned on rank `dst` only (None elsewhere) and lag the submissions by up to two frames."""
+
+    def __init__(self, params, width, channels, device, dtype=torch.float32, group=None, dst=0):
+        self.params, self.group, self.dst = params, group, dst
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        rows, rows_max, index_padded, _, _ = layout(params, self.world)
+        self.rows_max = max(rows_max, 1)
+        shape = (self.rows_max, width, channels)
+        self.send = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(2)]
+        self.recv = None
+        if self.world > 1 and self.rank == dst:
+            self.recv = [torch.empty((self.world,) + shape, dtype=dtype, device=device) for _ in range(2)]
+            self.index = index_padded.to(device)
+        self.work = [None, None]
+        self.turn = 0
+        self.done = None
+
+    def _finish(self, b):
+        """Frame of buffer b: wait for its gather and put the rows in image order."""
+        if self.work[b] is None:
+            return None
+        if self.work[b] is not True:
+            self.work[b].wait()
+        self.work[b] = None
+        if self.world == 1:
+            return self.send[b][: self.params.height].clone()
+        if self.rank != self.dst:
+            return None
+        flat = self.recv[b].view((self.world * self.rows_max,) + tuple(self.send[b].shape[1:]))
+        return flat.index_select(0, self.index)
+
+    def acquire(self):
+        self.done = self._finish(self.turn)
+        return self.send[self.turn]
+
+    def submit(self):
+        b = self.turn
+        if self.world == 1:
+            self.work[b] = True
+        elif self.rank == self.dst:
+            self.work[b] = dist.gather(self.send[b], list(self.recv[b].unbind(0)), dst=self.dst, group=self.group, async_op=True)
+        else:
+            self.work[b] = dist.gather(self.send[b], None, dst=self.dst, group=self.group, async_op=True)
+        self.turn ^= 1
+        out, self.done = self.done, None
+        return out
+
+    def drain(self):
+        out = [self._finish(self.turn), self._finish(self.turn ^ 1)]
+        return [x for x in out if x is not None] if (self.world == 1 or self.rank == self.dst) else []

@@ -72,3 +72,69 @@ def test_single_process_path_is_identity():
     assert torch.equal(tiles.gather_rows(local, p), local)
     idx = tiles.row_permutation(R.default_params(4, 10, row_tile=2), 3)
     assert sorted(idx.tolist()) == list(range(10))
+
+
+def _pipeline_worker(rank, world, port, width, height, tile, frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        base = R.default_params(width, height, row_tile=tile)
+        mine = tiles.part_params(base, world, rank)
+        lib = L.lib()
+        rows = lib.rtamd_local_rows(C.byref(mine))
+        pipe = tiles.GatherPipeline(mine, width, 3, "cpu")
+        got = []
+        for k in range(frames):
+            buf = pipe.acquire()
+            for lr in range(rows):
+                buf[lr, :, 0] = lib.rtamd_global_row(C.byref(mine), lr)
+                buf[lr, :, 1] = k
+                buf[lr, :, 2] = rank
+            img = pipe.submit()
+            if img is not None:
+                got.append(img.numpy().copy())
+        got += [x.numpy().copy() for x in pipe.drain()]
+        if rank == 0:
+            q.put(got)
+        else:
+            assert got == []
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,height,tile,frames", [(2, 37, 8, 5), (3, 50, 4, 1), (2, 16, 16, 2)])
+def test_double_buffered_gather_returns_every_frame_in_order(world, height, tile, frames):
+    width = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, width, height, tile, frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len(got) == frames
+    ys = np.arange(height, dtype=np.float32)
+    for k, img in enumerate(got):
+        assert img.shape == (height, width, 3)
+        assert np.array_equal(img[:, 0, 0], ys)
+        assert (img[:, :, 1] == k).all()
+        assert np.array_equal(img[:, 0, 2], ((ys // tile) % world).astype(np.float32))
+
+
+def test_pipeline_single_process():
+    p = R.default_params(4, 6)
+    pipe = tiles.GatherPipeline(p, 4, 3, "cpu")
+    out = []
+    for k in range(3):
+        buf = pipe.acquire()
+        buf.fill_(k)
+        img = pipe.submit()
+        if img is not None:
+            out.append(img)
+    out += pipe.drain()
+    assert [float(x[0, 0, 0]) for x in out] == [0.0, 1.0, 2.0]
