@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--row-tile", type=int, default=16)
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH: faces per leaf (0 = library default)")
     ap.add_argument("--sah-bins", type=int, default=0, help="BVH: SAH bins (0 = library default)")
+    ap.add_argument("--builder", type=int, default=0, help="0 = host SAH builder, 1 = on-GPU Morton-order builder")
     ap.add_argument("--shadow-rays", type=int, default=0, help="0 = candidate grids when possible, 1 = shadow rays walk the BVH")
     ap.add_argument("--primary-rays", type=int, default=0, help="0 = screen binning, 1 = primary rays walk the BVH")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample; 0 = skip")
@@ -156,7 +157,7 @@ def main():
     name = a.workload or ("bunny_1080p" if world == 1 else "field_4k")
     w = workloads.get(name)
     t0 = time.time()
-    fly, params, cam = workloads.make_flyscene(w, max_leaf_faces=a.max_leaf, sah_bins=a.sah_bins, shadow_rays=a.shadow_rays, primary_rays=a.primary_rays)
+    fly, params, cam = workloads.make_flyscene(w, max_leaf_faces=a.max_leaf, sah_bins=a.sah_bins, shadow_rays=a.shadow_rays, primary_rays=a.primary_rays, builder=a.builder)
     info = fly.info()
     init_s = time.time() - t0
     W, H = w["width"], w["height"]
@@ -216,10 +217,10 @@ def main():
     # ---- reduce over ranks: slowest rank's time, all ranks' rays
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     rays = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_bounce], dtype=torch.float64, device=dev)
-    kern = torch.tensor([st.ms_trace, st.ms_shadow, st.launches_trace, st.launches_shadow, st.ms_compact, st.ms_shade, st.ms_frames],
-                        dtype=torch.float64, device=dev)
+    kern = torch.tensor([st.ms_trace, st.ms_shadow, st.launches_trace, st.launches_shadow, st.ms_compact, st.ms_shade, st.ms_frames,
+                         st.ms_raster, st.launches_raster], dtype=torch.float64, device=dev)
     wk = torch.tensor([work.box_tests[0], work.tri_plane[0], work.tri_edge[0], work.box_tests[1], work.tri_plane[1], work.tri_edge[1],
-                       work.hits], dtype=torch.float64, device=dev)
+                       work.box_tests[2], work.tri_plane[2], work.tri_edge[2]], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
@@ -254,32 +255,35 @@ def main():
                 "parallelism": "row tiles of %d rows round-robin over %d GPU(s), one float32 gather per frame, overlapped with the next frame" % (a.row_tile, world),
                 "shadow_rays": "per-sample candidate grids (%d face references)" % info.shadow_grid_entries if info.shadow_grid_entries else "BVH walk",
                 "bvh": {"nodes": int(info.num_nodes), "leaves": int(info.num_leaves), "depth": int(info.depth),
-                        "build_ms": round(float(info.build_ms), 1), "device_MB": round(info.device_bytes / 1e6, 2)},
+                        "build_ms": round(float(info.build_ms), 1),
+                        "builder": ("host SAH", "device LBVH")[int(info.builder)], "hierarchy_ms": round(float(info.hierarchy_ms), 1), "device_MB": round(info.device_bytes / 1e6, 2)},
                 "scene_init_s": round(init_s, 2),
             },
         }
-        # ---- roofline of the dominant kernel (slowest rank's event times; work summed over ranks / ranks)
-        if not a.no_kernel_events and kmax[2].item() > 0 and kmax[3].item() > 0:
-            ms_trace = kmax[0].item() / kmax[2].item()
-            ms_shadow = kmax[1].item() / kmax[3].item()
-            launches_per_frame = (kmax[2].item() / a.steps, kmax[3].item() / a.steps)
+        # ---- roofline of the dominant kernel (slowest rank's event times; work summed over ranks / ranks).
+        # Three groups are timed: the BVH walk for closest hits, the shadow-ray kernel, and the screen-bin pass of
+        # the primary rays (three small binning kernels + raster_kernel, timed as one).
+        if not a.no_kernel_events and kmax[3].item() > 0:
+            group_ms = [kmax[0].item(), kmax[1].item(), kmax[7].item()]
+            group_launches = [kmax[2].item(), kmax[3].item(), kmax[8].item()]
             wl = wk.cpu().numpy() / world  # per-GPU share of one frame
-            flops = [wl[0] * FLOPS_BOX + wl[1] * FLOPS_PLANE + wl[2] * FLOPS_EDGE,
-                     wl[3] * FLOPS_BOX + wl[4] * FLOPS_PLANE + wl[5] * FLOPS_EDGE]
-            byts = [wl[0] * BYTES_BOX + wl[1] * BYTES_PLANE + wl[2] * BYTES_EDGE,
-                    wl[3] * BYTES_BOX + wl[4] * BYTES_PLANE + wl[5] * BYTES_EDGE]
-            k = 0 if kmax[0].item() >= kmax[1].item() else 1
-            kname = ("walk_kernel<closest hit>", "shadow_grid_kernel" if info.shadow_grid_entries else "walk_kernel<shadow>")[k]
-            per_launch_ms = (ms_trace, ms_shadow)[k]
-            flops_launch = flops[k] / launches_per_frame[k]
-            bytes_launch = byts[k] / launches_per_frame[k]
+            flops = [wl[3 * g] * FLOPS_BOX + wl[3 * g + 1] * FLOPS_PLANE + wl[3 * g + 2] * FLOPS_EDGE for g in range(3)]
+            byts = [wl[3 * g] * BYTES_BOX + wl[3 * g + 1] * BYTES_PLANE + wl[3 * g + 2] * BYTES_EDGE for g in range(3)]
+            k = max(range(3), key=lambda g: group_ms[g])
+            closest_key = "walk_kernel<1, false>" if group_launches[2] > 0 or w["max_reflections"] > 0 else "walk_kernel<0, false>"
+            shadow_key = "shadow_grid_kernel<false>" if info.shadow_grid_entries else "walk_kernel<2, false>"
+            kname = ("walk_kernel<closest hit>", "shadow_grid_kernel" if info.shadow_grid_entries else "walk_kernel<shadow>",
+                     "raster_kernel (+ bin_count, bin_offsets, bin_fill)")[k]
+            launches_per_frame = group_launches[k] / a.steps
+            per_launch_ms = group_ms[k] / group_launches[k]
+            flops_launch = flops[k] / launches_per_frame
+            bytes_launch = byts[k] / launches_per_frame
             ach = flops_launch / (per_launch_ms * 1e-3) / 1e12
             out["roofline"] = {"kernel": kname, "bound": "valu", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None,
-                               "avg_launch_ms": round(per_launch_ms, 4), "launches_per_frame": launches_per_frame[k],
-                               "share_of_frame": round(kmax[k].item() / max(kmax[6].item(), 1e-9), 3)}
-            shadow_key = "shadow_grid_kernel<false>" if info.shadow_grid_entries else "walk_kernel<2, false>"
-            traffic, traffic_src = pmc_traffic(name, ("walk_kernel<1, false>" if w["max_reflections"] > 0 else "walk_kernel<0, false>", shadow_key)[k])
+                               "avg_launch_ms": round(per_launch_ms, 4), "launches_per_frame": launches_per_frame,
+                               "share_of_frame": round(group_ms[k] / max(kmax[6].item(), 1e-9), 3)}
+            traffic, traffic_src = pmc_traffic(name, (closest_key, shadow_key, "raster_kernel<false>")[k])
             out["roofline"]["traffic"] = None if traffic is None else round(traffic)
             if traffic is not None:
                 out["roofline"]["traffic_unit"] = "bytes/launch at the L2's memory side, (2*FETCH_SIZE + WRITE_SIZE) KiB, from profiles/" + traffic_src
@@ -288,12 +292,13 @@ def main():
             out["roofline_hbm"] = {"kernel": kname, "bound": "hbm", "achieved": round(ach_b, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": round(ach_b / PEAK_HBM_GBS, 4), "traffic": None if traffic is None else round(traffic),
                                    "note": "algorithmic bytes are served by L2 / Infinity Cache; the scene is %.1f MB" % (info.device_bytes / 1e6)}
-            out["kernels"] = {"trace_ms_per_frame": round(kmax[0].item() / a.steps, 4), "shadow_ms_per_frame": round(kmax[1].item() / a.steps, 4),
+            out["kernels"] = {"trace_ms_per_frame": round(group_ms[0] / a.steps, 4), "shadow_ms_per_frame": round(group_ms[1] / a.steps, 4),
+                              "raster_ms_per_frame": round(group_ms[2] / a.steps, 4),
                               "compact_ms_per_frame": round(kmax[4].item() / a.steps, 4), "shade_ms_per_frame": round(kmax[5].item() / a.steps, 4),
                               "frame_ms_events": round(kmax[6].item() / a.steps, 4),
-                              "tests_per_ray": {"box": round((wk[0].item() + wk[3].item()) / rays_frame, 2),
-                                                "tri_plane": round((wk[1].item() + wk[4].item()) / rays_frame, 2),
-                                                "tri_edge": round((wk[2].item() + wk[5].item()) / rays_frame, 2)}}
+                              "tests_per_ray": {"box": round(float(wk[0::3].sum().item()) / rays_frame, 2),
+                                                "tri_plane": round(float(wk[1::3].sum().item()) / rays_frame, 2),
+                                                "tri_edge": round(float(wk[2::3].sum().item()) / rays_frame, 2)}}
         if world == 1:
             # the same frame through the blocking host-buffer entry point (upload of nothing, download of
             # rgb + face ids over PCIe): reported beside `value`, never as `value`

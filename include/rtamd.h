@@ -89,12 +89,19 @@ typedef struct {
 #define RTAMD_SHADOW_RAYS_AUTO 0 /* per-sample candidate grids when every sample direction allows it   */
 #define RTAMD_SHADOW_RAYS_TREE 1 /* shadow rays walk the BVH like every other ray                       */
 
+/* Who builds the hierarchy that replaces boundingBox::splitBox (src/boundingBox.h:69-194).  Images do not
+ * depend on the choice; only the time to build and the time per frame do. */
+#define RTAMD_BUILDER_HOST_SAH 0    /* binned surface-area heuristic on the host: best tree, seconds for 10^6 faces */
+#define RTAMD_BUILDER_DEVICE_LBVH 1 /* Morton-order radix tree built on the GPU: milliseconds, somewhat slower rays;
+                                       falls back to the host builder when it does not apply (rtamd_scene_info::builder) */
+
 typedef struct {
     int32_t max_leaf_faces; /* 1..15; 0 = default (4)                                              */
     int32_t sah_bins;       /* 4..64; 0 = default (16)                                             */
     int32_t shadow_rays;    /* RTAMD_SHADOW_RAYS_*                                                 */
     int32_t primary_rays;   /* RTAMD_PRIMARY_RAYS_*                                                */
-    int32_t reserved[4];
+    int32_t builder;        /* RTAMD_BUILDER_*                                                     */
+    int32_t reserved[3];
 } rtamd_build_params;
 
 /* What tracePixels/screenToWorld read from Tucano::Camera (camera.hpp:84,118-121,158-181). */
@@ -139,21 +146,24 @@ typedef struct {
     uint64_t rays_shadow;  /* num_lights*samples_per_light per hit (src/flyscene.cpp:880-887)     */
     uint64_t rays_bounce;  /* reflection rays (src/flyscene.cpp:636)                              */
     uint64_t hits;         /* closest-hit queries that found a surface                            */
-    /* RTAMD_FLAG_COUNT_WORK only, most recent frame; [0] = closest-hit kernel (primary + bounce
-     * rays), [1] = shadow-ray kernel: */
-    uint64_t box_tests[2]; /* ray/AABB slab tests                                                 */
-    uint64_t tri_plane[2]; /* plane-distance evaluations                                          */
-    uint64_t tri_edge[2];  /* faces that reached the edge tests                                   */
+    /* RTAMD_FLAG_COUNT_WORK only, most recent frame; [0] = BVH walk for closest hits (bounce rays, and
+     * primary rays when they are not binned), [1] = shadow-ray kernel (candidate grids or BVH walk),
+     * [2] = screen-bin pass of the primary rays: */
+    uint64_t box_tests[3]; /* ray/AABB slab tests                                                 */
+    uint64_t tri_plane[3]; /* plane-distance evaluations                                          */
+    uint64_t tri_edge[3];  /* faces that reached the edge tests                                   */
     /* RTAMD_FLAG_TIME_KERNELS only: HIP-event durations in milliseconds, summed over every launch
      * and frame enqueued since the previous rtamd_render_stats call: */
-    float ms_trace;        /* closest-hit traversal kernel                                        */
-    float ms_shadow;       /* shadow-ray traversal kernel                                         */
+    float ms_trace;        /* closest-hit BVH walk kernel                                         */
+    float ms_shadow;       /* shadow-ray kernel                                                   */
     float ms_compact;      /* hit-list compaction kernel                                          */
     float ms_shade;        /* shading kernel                                                      */
     float ms_frames;       /* first launch to last launch of each frame, summed                   */
     int32_t launches_trace;
     int32_t launches_shadow;
     int32_t frames;
+    float ms_raster;       /* screen-bin pass: bin count, offsets, fill and raster kernels        */
+    int32_t launches_raster; /* passes, not kernels                                               */
 } rtamd_stats;
 
 typedef struct {
@@ -167,6 +177,8 @@ typedef struct {
     float build_ms;           /* host BVH (and shadow grid) build                                 */
     float upload_ms;
     uint64_t shadow_grid_entries; /* face references in the shadow-ray grids, 0 = tree walk        */
+    int32_t builder;          /* RTAMD_BUILDER_* that produced the hierarchy in use               */
+    float hierarchy_ms;       /* part of build_ms spent on the hierarchy alone                    */
 } rtamd_scene_info;
 
 const char *rtamd_last_error(void);

@@ -12,6 +12,7 @@ FACE_SPHERE, FACE_MISS = -1, -2
 FLAG_COUNT_WORK, FLAG_TIME_KERNELS, FLAG_SINGLE_STREAM = 1, 2, 4
 SHADOW_RAYS_AUTO, SHADOW_RAYS_TREE = 0, 1
 PRIMARY_RAYS_AUTO, PRIMARY_RAYS_TREE = 0, 1
+BUILDER_HOST_SAH, BUILDER_DEVICE_LBVH = 0, 1
 
 
 class Material(C.Structure):
@@ -44,7 +45,7 @@ class SceneDesc(C.Structure):
 
 class BuildParams(C.Structure):
     _fields_ = [("max_leaf_faces", C.c_int32), ("sah_bins", C.c_int32), ("shadow_rays", C.c_int32), ("primary_rays", C.c_int32),
-                ("reserved", C.c_int32 * 4)]
+                ("builder", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class Camera(C.Structure):
@@ -65,9 +66,10 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [
         ("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_bounce", C.c_uint64), ("hits", C.c_uint64),
-        ("box_tests", C.c_uint64 * 2), ("tri_plane", C.c_uint64 * 2), ("tri_edge", C.c_uint64 * 2),
+        ("box_tests", C.c_uint64 * 3), ("tri_plane", C.c_uint64 * 3), ("tri_edge", C.c_uint64 * 3),
         ("ms_trace", C.c_float), ("ms_shadow", C.c_float), ("ms_compact", C.c_float), ("ms_shade", C.c_float),
         ("ms_frames", C.c_float), ("launches_trace", C.c_int32), ("launches_shadow", C.c_int32), ("frames", C.c_int32),
+        ("ms_raster", C.c_float), ("launches_raster", C.c_int32),
     ]
 
     @property
@@ -88,7 +90,7 @@ class SceneInfo(C.Structure):
     _fields_ = [
         ("num_faces", C.c_int32), ("num_device_faces", C.c_int32), ("num_nodes", C.c_int32), ("num_leaves", C.c_int32),
         ("depth", C.c_int32), ("device", C.c_int32), ("device_bytes", C.c_uint64), ("build_ms", C.c_float),
-        ("upload_ms", C.c_float), ("shadow_grid_entries", C.c_uint64),
+        ("upload_ms", C.c_float), ("shadow_grid_entries", C.c_uint64), ("builder", C.c_int32), ("hierarchy_ms", C.c_float),
     ]
 
     def as_dict(self):

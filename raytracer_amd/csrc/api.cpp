@@ -13,13 +13,16 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rtamd.h"
 #include "bvh.hpp"
+#include "lbvh.h"
 #include "shadow_grid.hpp"
 #include "device_types.h"
 #include "kernels.h"
@@ -301,9 +304,23 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     std::vector<int32_t> rank;
     reference_face_rank(mesh, rank);
     FlatBvh bvh;
-    build_flat_bvh(mesh, rank, build ? build->max_leaf_faces : 0, build ? build->sah_bins : 0, bvh);
+    const double th0 = now_ms();
+    const bool verbose = std::getenv("RTAMD_VERBOSE_BUILD") != nullptr;
+    int builder_used = RTAMD_BUILDER_HOST_SAH;
+    if (build && build->builder == RTAMD_BUILDER_DEVICE_LBVH) {
+        std::vector<TriRecord> records;
+        gather_face_records(mesh, rank, records);
+        std::string why;
+        if (build_lbvh_device(records, build->max_leaf_faces, bvh, why)) builder_used = RTAMD_BUILDER_DEVICE_LBVH;
+    } else if (build && build->builder != RTAMD_BUILDER_HOST_SAH) {
+        delete s;
+        return fail(RTAMD_ERR_INVALID, "unknown builder %d", build->builder);
+    }
+    if (builder_used == RTAMD_BUILDER_HOST_SAH)
+        build_flat_bvh(mesh, rank, build ? build->max_leaf_faces : 0, build ? build->sah_bins : 0, bvh);
+    const double th1 = now_ms();
     // The walk keeps at most stack_need entries; narrower nodes need fewer (a binary tree needs its depth).
-    for (int width = 3; bvh.stack_need > kStackEntries && width >= 2; --width) collapse_bvh(bvh, width);
+    for (int width = 3; bvh.stack_need > kStackEntries && width >= 2 && !bvh.nodes.empty(); --width) collapse_bvh(bvh, width);
     if (bvh.stack_need > kStackEntries) {
         delete s;
         return fail(RTAMD_ERR_LIMIT, "BVH needs %d traversal stack entries, the kernels hold %d", bvh.stack_need, kStackEntries);
@@ -312,22 +329,37 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     ShadowGrids grids;
     if (!(build && build->shadow_rays == RTAMD_SHADOW_RAYS_TREE))
         build_shadow_grids(bvh, d->light_samples, d->num_lights * d->samples_per_light, grids);
+    const double tg = now_ms();
     std::vector<ShadeRecord> shade((size_t)d->num_faces);
-    for (int32_t f = 0; f < d->num_faces; ++f) {
-        ShadeRecord &r = shade[f];
-        std::memset(&r, 0, sizeof r);
-        const int32_t *id = d->face_vertex_ids + 3 * (size_t)f;
-        std::memcpy(r.v0, d->vertices + 3 * (size_t)id[0], 12);
-        std::memcpy(r.v1, d->vertices + 3 * (size_t)id[1], 12);
-        std::memcpy(r.v2, d->vertices + 3 * (size_t)id[2], 12);
-        std::memcpy(r.n0, d->normals + 3 * (size_t)id[0], 12);
-        std::memcpy(r.n1, d->normals + 3 * (size_t)id[1], 12);
-        std::memcpy(r.n2, d->normals + 3 * (size_t)id[2], 12);
-        std::memcpy(r.fn, d->face_normals + 3 * (size_t)f, 12);
-        r.material = d->face_material_ids[f];
-        if (textured) std::memcpy(r.tc, d->face_texcoords + 6 * (size_t)f, 24);
+    auto fill_shade = [&](int32_t f0, int32_t f1) {
+        for (int32_t f = f0; f < f1; ++f) {
+            ShadeRecord &r = shade[f];
+            std::memset(&r, 0, sizeof r);
+            const int32_t *id = d->face_vertex_ids + 3 * (size_t)f;
+            std::memcpy(r.v0, d->vertices + 3 * (size_t)id[0], 12);
+            std::memcpy(r.v1, d->vertices + 3 * (size_t)id[1], 12);
+            std::memcpy(r.v2, d->vertices + 3 * (size_t)id[2], 12);
+            std::memcpy(r.n0, d->normals + 3 * (size_t)id[0], 12);
+            std::memcpy(r.n1, d->normals + 3 * (size_t)id[1], 12);
+            std::memcpy(r.n2, d->normals + 3 * (size_t)id[2], 12);
+            std::memcpy(r.fn, d->face_normals + 3 * (size_t)f, 12);
+            r.material = d->face_material_ids[f];
+            if (textured) std::memcpy(r.tc, d->face_texcoords + 6 * (size_t)f, 24);
+        }
+    };
+    if (d->num_faces < (1 << 16)) {
+        fill_shade(0, d->num_faces);
+    } else {
+        const int workers = 8;
+        std::vector<std::thread> pool;
+        for (int w = 0; w < workers; ++w)
+            pool.emplace_back(fill_shade, (int32_t)((int64_t)d->num_faces * w / workers), (int32_t)((int64_t)d->num_faces * (w + 1) / workers));
+        for (std::thread &t : pool) t.join();
     }
     const double t1 = now_ms();
+    if (verbose)
+        std::fprintf(stderr, "rtamd: scene build, %d faces: face ranks %.1f ms, hierarchy %.1f ms, shadow grids %.1f ms, shading records %.1f ms\n",
+                     d->num_faces, th0 - t0, th1 - th0, tg - th1, t1 - tg);
 
     // ---- upload
     uint64_t bytes = 0;
@@ -402,6 +434,8 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     s->info.device = dev;
     s->info.device_bytes = bytes;
     s->info.build_ms = (float)(t1 - t0);
+    s->info.builder = builder_used;
+    s->info.hierarchy_ms = (float)(th1 - th0);
     s->info.upload_ms = (float)(t2 - t1);
     *out = s;
     return RTAMD_OK;
@@ -583,9 +617,9 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
                 const bool spawn = d + 1 < depths;
                 // ---- closest hits
                 stream_of_launch = geo;
-                if ((rc = begin(0)) != RTAMD_OK) return rc;
+                if ((rc = begin(d == 0 && bins_ok ? 6 : 0)) != RTAMD_OK) return rc;
                 if (d == 0 && bins_ok) launch_primary_bins(count, s->ds, fc, ws_frame, s->info.num_device_faces, geo);
-                launch_walk_closest(d == 0, count, s->ds, fc, ws_frame, stage, d, geo);
+                launch_walk_closest(d == 0, count, s->ds, fc, ws_frame, stage, d, geo); // after the bins: only on their overflow
                 if ((rc = end()) != RTAMD_OK) return rc;
                 if (two_streams && d >= 2) HIP_TRY(hipStreamWaitEvent(geo, shaded(d - 2), 0));
                 if ((rc = begin(2)) != RTAMD_OK) return rc;
@@ -638,7 +672,7 @@ int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
     if (!s->have_frame) return RTAMD_OK;
     HIP_TRY(hipStreamSynchronize(s->last_stream));
     std::vector<StageCounters> sc((size_t)kMaxStages);
-    WorkCounters wc[2];
+    WorkCounters wc[3];
     HIP_TRY(hipMemcpy(sc.data(), s->ws.stage, sizeof(StageCounters) * kMaxStages, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(wc, s->ws.work, sizeof wc, hipMemcpyDeviceToHost));
     st->rays_primary = s->last_primary;
@@ -648,7 +682,7 @@ int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
         st->rays_shadow += (uint64_t)sc[i].hits * per_hit;
         st->rays_bounce += (uint64_t)sc[i].next;
     }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         st->box_tests[k] = wc[k].box_tests;
         st->tri_plane[k] = wc[k].tri_plane;
         st->tri_edge[k] = wc[k].tri_edge;
@@ -661,6 +695,7 @@ int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
         if (s->events[i].kind == 2) st->ms_compact += ms;
         if (s->events[i].kind == 3) st->ms_shade += ms;
         if (s->events[i].kind == 5) st->ms_frames += ms, ++st->frames;
+        if (s->events[i].kind == 6) st->ms_raster += ms, ++st->launches_raster;
     }
     s->events_used = 0;
     return RTAMD_OK;

@@ -1,10 +1,12 @@
 #include "bvh.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 namespace rtamd {
 
@@ -49,12 +51,13 @@ namespace {
 struct RankBuilder {
     const MeshView &m;
     std::vector<int32_t> &rank;
-    int32_t next = 0;
 
-    void split(const std::vector<int32_t> &faces, const float *bmin, const float *bmax) {
+    // Every face lands in exactly one leaf, so the faces below a node take the ranks base .. base + n - 1
+    // whatever happens further down: the two halves of a large node can be replayed by different threads.
+    void split(const std::vector<int32_t> &faces, const float *bmin, const float *bmax, int32_t base, int forks_left) {
         const size_t n = faces.size();
         if (n < 10) { // baseCase, boundingBox.h:34,73
-            for (int32_t f : faces) rank[f] = next++;
+            for (int32_t f : faces) rank[f] = base++;
             return;
         }
         const float side[3] = {bmax[0] - bmin[0], bmax[1] - bmin[1], bmax[2] - bmin[2]};
@@ -89,10 +92,17 @@ struct RankBuilder {
             if (to_upper ? !in_upper : !in_lower) ++straddlers;
         }
         if ((double)lower.size() < 0.8 * (double)n && (double)upper.size() < 0.8 * (double)n) {
-            split(lower, loMin, loMax);
-            split(upper, upMin, upMax);
+            const int32_t upper_base = base + (int32_t)lower.size();
+            if (forks_left > 0 && n >= 32768) {
+                std::thread other([&] { split(lower, loMin, loMax, base, forks_left - 1); });
+                split(upper, upMin, upMax, upper_base, forks_left - 1);
+                other.join();
+            } else {
+                split(lower, loMin, loMax, base, 0);
+                split(upper, upMin, upMax, upper_base, 0);
+            }
         } else {
-            for (int32_t f : faces) rank[f] = next++;
+            for (int32_t f : faces) rank[f] = base++;
         }
     }
 };
@@ -115,7 +125,7 @@ void reference_face_rank(const MeshView &mesh, std::vector<int32_t> &rank) {
     std::vector<int32_t> all((size_t)mesh.num_faces);
     std::iota(all.begin(), all.end(), 0);
     RankBuilder rb{mesh, rank};
-    rb.split(all, bmin, bmax);
+    rb.split(all, bmin, bmax, 0, 4); // up to 16 threads at the fourth level
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -140,9 +150,12 @@ struct SahBuilder {
     static constexpr float kTraversalCost = 1.0f;
     static constexpr float kTriCost = 2.0f; // the exact plane + three-edge test costs about two node visits
 
+    std::atomic<int> leaves{0}, deepest{0};
+
+    // Every prim ends in exactly one leaf and leaves keep the order of `prims`: record i belongs at position i.
     int32_t make_leaf(int lo, int hi, Box &box) {
         box.reset();
-        const int32_t first = (int32_t)out.tris.size();
+        const int32_t first = lo;
         for (int i = lo; i < hi; ++i) {
             const Prim &p = prims[i];
             box.grow(p.box);
@@ -157,16 +170,19 @@ struct SahBuilder {
             std::memcpy(t.v2, vtx(m, id[2]), 12);
             t.face = f;
             t.rank = rank[f];
-            out.tris.push_back(t);
+            out.tris[(size_t)i] = t;
         }
-        ++out.num_leaves;
+        leaves.fetch_add(1, std::memory_order_relaxed);
         return ~((first << 4) | (hi - lo));
     }
 
-    // Returns the child reference (inner index or encoded leaf) and the bounds of the subtree.
-    int32_t build(int lo, int hi, int depth, Box &box) {
+    // Returns the child reference (inner index into `nodes`, or encoded leaf) and the bounds of the subtree.
+    // Large nodes hand their second half to another thread, which builds into a vector of its own; it is
+    // appended behind the first half's nodes, so the node order is the one a serial build gives.
+    int32_t build(int lo, int hi, int depth, Box &box, std::vector<BvhNode> &nodes, int forks_left) {
         const int n = hi - lo;
-        out.depth = std::max(out.depth, depth);
+        for (int seen = deepest.load(std::memory_order_relaxed); seen < depth && !deepest.compare_exchange_weak(seen, depth);) {
+        }
         // depth budget: how many levels a balanced split still needs
         int need = 0;
         while (((size_t)max_leaf << need) < (size_t)n) ++need;
@@ -246,12 +262,27 @@ struct SahBuilder {
         if (mid == lo || mid == hi) mid = lo + n / 2;
         if (n <= max_leaf && (mid == lo || mid == hi)) return make_leaf(lo, hi, box);
 
-        const int32_t me = (int32_t)out.nodes.size();
-        out.nodes.emplace_back();
+        const int32_t me = (int32_t)nodes.size();
+        nodes.emplace_back();
         Box b0, b1;
-        const int32_t c0 = build(lo, mid, depth + 1, b0);
-        const int32_t c1 = build(mid, hi, depth + 1, b1);
-        BvhNode &nd = out.nodes[me];
+        int32_t c0, c1;
+        if (forks_left > 0 && n >= 16384) {
+            std::vector<BvhNode> second;
+            std::thread other([&] { c1 = build(mid, hi, depth + 1, b1, second, forks_left - 1); });
+            c0 = build(lo, mid, depth + 1, b0, nodes, forks_left - 1);
+            other.join();
+            const int32_t shift = (int32_t)nodes.size();
+            for (BvhNode &moved : second) {
+                if (moved.child[0] >= 0) moved.child[0] += shift;
+                if (moved.child[1] >= 0) moved.child[1] += shift;
+            }
+            if (c1 >= 0) c1 += shift;
+            nodes.insert(nodes.end(), second.begin(), second.end());
+        } else {
+            c0 = build(lo, mid, depth + 1, b0, nodes, 0);
+            c1 = build(mid, hi, depth + 1, b1, nodes, 0);
+        }
+        BvhNode &nd = nodes[me];
         nd.x[0] = b0.lo[0], nd.x[1] = b0.hi[0], nd.x[2] = b1.lo[0], nd.x[3] = b1.hi[0];
         nd.y[0] = b0.lo[1], nd.y[1] = b0.hi[1], nd.y[2] = b1.lo[1], nd.y[3] = b1.hi[1];
         nd.z[0] = b0.lo[2], nd.z[1] = b0.hi[2], nd.z[2] = b1.lo[2], nd.z[3] = b1.hi[2];
@@ -290,13 +321,15 @@ void build_flat_bvh(const MeshView &mesh, const std::vector<int32_t> &rank, int 
         sb.prims.push_back(p);
     }
     out.num_device_faces = (int)sb.prims.size();
-    out.tris.reserve(sb.prims.size());
+    out.tris.resize(sb.prims.size());
     out.nodes.reserve(sb.prims.size() / 2 + 2);
 
     const int n = (int)sb.prims.size();
     Box rb;
     int32_t root = 0;
-    if (n > 0) root = sb.build(0, n, 0, rb);
+    if (n > 0) root = sb.build(0, n, 0, rb, out.nodes, 4); // up to 16 threads at the fourth level
+    out.num_leaves = sb.leaves.load();
+    out.depth = sb.deepest.load();
     if (n == 0 || root < 0) {
         // The kernels start at inner node 0: wrap a lone leaf (or nothing) in one node whose second
         // child is a leaf with zero records.  Its inverted box does NOT keep rays out (the slab test
@@ -319,6 +352,27 @@ void build_flat_bvh(const MeshView &mesh, const std::vector<int32_t> &rank, int 
         out.depth = std::max(out.depth, 1);
     }
     collapse_bvh(out, 4);
+}
+
+void gather_face_records(const MeshView &m, const std::vector<int32_t> &rank, std::vector<TriRecord> &out) {
+    out.clear();
+    out.reserve((size_t)m.num_faces);
+    for (int32_t f = 0; f < m.num_faces; ++f) {
+        const float *n = m.face_normals + 3 * (size_t)f;
+        const float nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+        if (!(nn > 0.0f) || !std::isfinite(nn) || !std::isfinite(m.face_origin_distance[f])) continue; // as build_flat_bvh
+        const int32_t *id = m.face_vertex_ids + 3 * (size_t)f;
+        TriRecord t;
+        std::memset(&t, 0, sizeof t);
+        std::memcpy(t.n, n, 12);
+        t.d = m.face_origin_distance[f];
+        std::memcpy(t.v0, vtx(m, id[0]), 12);
+        std::memcpy(t.v1, vtx(m, id[1]), 12);
+        std::memcpy(t.v2, vtx(m, id[2]), 12);
+        t.face = f;
+        t.rank = rank[f];
+        out.push_back(t);
+    }
 }
 
 namespace {

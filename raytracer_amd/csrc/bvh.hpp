@@ -91,6 +91,9 @@ void reference_face_rank(const MeshView &mesh, std::vector<int32_t> &rank);
 // Binned-SAH build over the faces whose stored normal is finite and non-zero.
 void build_flat_bvh(const MeshView &mesh, const std::vector<int32_t> &rank, int max_leaf_faces, int sah_bins, FlatBvh &out);
 
+// The records of the faces build_flat_bvh would keep, in face order (input of the on-GPU builder).
+void gather_face_records(const MeshView &mesh, const std::vector<int32_t> &rank, std::vector<TriRecord> &out);
+
 // nodes -> nodes4 with at most `max_children` (2..4) children per node: repeatedly replaces the inner
 // child of largest surface area by its two children.  Fills depth4 and stack_need.
 void collapse_bvh(FlatBvh &bvh, int max_children);

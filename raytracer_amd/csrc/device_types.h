@@ -96,7 +96,7 @@ struct Workspace {
     // throughput later by the shading kernel of the parent depth.
     float *queue[3];
     StageCounters *stage; // kMaxStages
-    WorkCounters *work;   // [0] closest-hit kernel, [1] shadow kernel
+    WorkCounters *work;   // [0] closest-hit walk, [1] shadow kernel, [2] screen-bin raster
     // screen binning of the primary rays; bin_entries == nullptr: not in use
     BinState *bin_state;
     int32_t *bin_count;   // per bin: faces whose projection touches it; then the fill cursor

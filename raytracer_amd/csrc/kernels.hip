@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst 
             ws.slot_t[slot] = tbest;
         }
     }
-    if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work);
+    if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 2);
 }
 
 // ---------------------------------------------------------------------------------------------

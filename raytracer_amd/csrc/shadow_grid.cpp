@@ -127,7 +127,7 @@ void build_shadow_grids(const FlatBvh &bvh, const float *samples, int num_sample
     if (!std::isfinite(scale)) return;
 
     std::vector<OneGrid> grids((size_t)num_samples);
-    const int workers = std::max(1, std::min(num_samples, std::min(8, (int)std::thread::hardware_concurrency())));
+    const int workers = std::max(1, std::min(num_samples, std::min(16, (int)std::thread::hardware_concurrency())));
     std::vector<std::thread> pool;
     for (int w = 0; w < workers; ++w)
         pool.emplace_back([&, w] {

@@ -31,7 +31,7 @@ def _iptr(a):
 class Flyscene:
     def __init__(self, model=None, arrays=None, lights=None, hard_shadow=True, soft_points=12, soft_radius=0.3,
                  spheres=(), normalize_model=True, output="result.ppm", max_leaf_faces=0, sah_bins=0, textures=None,
-                 shadow_rays=0, primary_rays=0):
+                 shadow_rays=0, primary_rays=0, builder=0):
         """model: OBJ path (default: the reference's resources/models/bunny.obj, src/flyscene.cpp:39).
         arrays: (vertices[nv,3], normals[nv,3] or None, faces[nf,3], face_material[nf], materials) with
         materials a list of dicts ka/kd/ks/shininess.  lights: list of (x, y, z) or (x, y, z, r, g, b);
@@ -82,10 +82,10 @@ class Flyscene:
             L.check(self.lib.rtfly_add_sphere(self.h, (C.c_float * 3)(*s[:3]), float(s[3])), "rtfly_add_sphere")
         L.check(self.lib.rtfly_set_normalize_model(self.h, int(normalize_model)), "rtfly_set_normalize_model")
         L.check(self.lib.rtfly_set_output(self.h, os.fsencode(output)), "rtfly_set_output")
-        if max_leaf_faces or sah_bins or shadow_rays or primary_rays:
+        if max_leaf_faces or sah_bins or shadow_rays or primary_rays or builder:
             b = L.BuildParams()
             b.max_leaf_faces, b.sah_bins, b.shadow_rays = int(max_leaf_faces), int(sah_bins), int(shadow_rays)
-            b.primary_rays = int(primary_rays)
+            b.primary_rays, b.builder = int(primary_rays), int(builder)
             L.check(self.lib.rtfly_set_build_params(self.h, C.byref(b)), "rtfly_set_build_params")
         self.width = self.height = 0
 

@@ -139,6 +139,56 @@ def test_screen_bins_and_tree_walk_agree_for_primary_rays(name, view):
             assert (ra["face_id"] >= 0).any()
 
 
+@pytest.mark.parametrize("name", ["NthTest", "toy_on_plane", "bunny", "reflect_test", "textured_quad", "glass"])
+def test_device_built_hierarchy_gives_the_same_frame(name):
+    """The hierarchy built on the GPU (Morton-order radix tree) replaces the host SAH tree without changing a bit
+    of the frame: every ray kind is sent through it (no bins, no grids) and compared with the default path."""
+    kw = dict(model=scene_path(name), output="")
+    a = R.Flyscene(**kw).initialize(120, 88)
+    b = R.Flyscene(builder=L.BUILDER_DEVICE_LBVH, primary_rays=L.PRIMARY_RAYS_TREE, shadow_rays=L.SHADOW_RAYS_TREE, **kw).initialize(120, 88)
+    c = R.Flyscene(builder=L.BUILDER_DEVICE_LBVH, max_leaf_faces=1, **kw).initialize(120, 88)
+    assert a.info().builder == L.BUILDER_HOST_SAH
+    assert b.info().builder == L.BUILDER_DEVICE_LBVH and c.info().builder == L.BUILDER_DEVICE_LBVH
+    assert b.info().num_device_faces == a.info().num_device_faces
+    for f in (a, b, c):
+        f.camera_translate(1.0, -0.5, 6.0)
+        f.camera_rotate(-0.1, 0.2)
+    ra = a.render()
+    assert (ra["face_id"] >= 0).any() and ra["stats"].rays_shadow > 0
+    for other in (b, c):
+        ro = other.render()
+        assert np.array_equal(ra["face_id"], ro["face_id"])
+        assert np.array_equal(ra["rgb"].view(np.uint32), ro["rgb"].view(np.uint32))
+        sa, so = ra["stats"], ro["stats"]
+        assert (sa.rays_primary, sa.rays_shadow, sa.rays_bounce, sa.hits) == (so.rays_primary, so.rays_shadow, so.rays_bounce, so.hits)
+
+
+def test_device_builder_on_a_large_mesh_and_its_fallback():
+    import torch
+
+    w = workloads.get("field2_mirrors_small")
+    frames = []
+    for build in (dict(), dict(builder=L.BUILDER_DEVICE_LBVH)):
+        fly, params, cam = workloads.make_flyscene(w, **build)
+        rgb = torch.zeros((w["height"], w["width"], 3), dtype=torch.float32, device="cuda")
+        fid = torch.zeros((w["height"], w["width"]), dtype=torch.int32, device="cuda")
+        fly.render_device(rgb, fid, camera=cam)
+        torch.cuda.synchronize()
+        frames.append((fly.info(), rgb.cpu().numpy(), fid.cpu().numpy(), fly.stats()))
+    (ia, rgb_a, fid_a, sa), (ib, rgb_b, fid_b, sb) = frames
+    assert ia.builder == L.BUILDER_HOST_SAH and ib.builder == L.BUILDER_DEVICE_LBVH and ib.num_device_faces == ia.num_device_faces
+    assert ib.hierarchy_ms < ia.hierarchy_ms
+    assert np.array_equal(fid_a, fid_b)
+    assert np.array_equal(rgb_a.view(np.uint32), rgb_b.view(np.uint32))
+    assert sa.rays_bounce == sb.rays_bounce > 0 and sa.rays_shadow == sb.rays_shadow
+    # one face: nothing to sort, the host builder takes over and says so
+    one = R.Flyscene(arrays=(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), None, np.array([[0, 1, 2]], np.int32),
+                             np.array([0], np.int32), [dict(ka=(0, 0, 0), kd=(1, 0, 0), ks=(0, 0, 0), shininess=1.0)]),
+                     builder=L.BUILDER_DEVICE_LBVH, output="").initialize(32, 32)
+    assert one.info().builder == L.BUILDER_HOST_SAH
+    assert (one.render()["face_id"] >= 0).any()
+
+
 def test_degenerate_sample_direction_falls_back_to_the_tree():
     # a light at the origin gives a zero shadow-ray direction (its hard-shadow sample): no grid can be built for it
     fly, orc = make_pair("glass", width=48, height=48, lights=[(0.0, 0.0, 0.0)], soft_points=0)
@@ -289,8 +339,11 @@ def test_counted_frame_matches_plain_frame():
     counted = fly.render()
     assert np.array_equal(plain["rgb"].view(np.uint32), counted["rgb"].view(np.uint32))
     st = counted["stats"]
-    assert st.box_tests[0] > 0 and st.box_tests[1] > 0 and st.tri_plane[0] >= st.tri_edge[0] > 0
-    assert st.launches_trace >= 1 and st.launches_shadow >= 1 and st.ms_frames > 0 and st.ms_shade > 0 and st.ms_compact > 0
+    # [0] BVH walk for closest hits, [1] shadow rays, [2] screen-bin pass of the primary rays (when it is used)
+    assert st.box_tests[0] > 0 and st.box_tests[1] > 0
+    assert st.tri_plane[0] + st.tri_plane[2] >= st.tri_edge[0] + st.tri_edge[2] > 0
+    assert st.launches_trace + st.launches_raster >= 2 and st.launches_shadow >= 1
+    assert st.ms_frames > 0 and st.ms_shade > 0 and st.ms_compact > 0 and st.ms_trace + st.ms_raster > 0
 
 
 def test_raytrace_scene_writes_the_reference_ppm(tmp_path):
