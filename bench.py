@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--row-tile", type=int, default=16)
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH: faces per leaf (0 = library default)")
     ap.add_argument("--sah-bins", type=int, default=0, help="BVH: SAH bins (0 = library default)")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="frames enqueued at a time, each on a stream of its own (1..4; at most 2 with several GPUs)")
     ap.add_argument("--builder", type=int, default=0, help="0 = host SAH builder, 1 = on-GPU Morton-order builder")
     ap.add_argument("--shadow-rays", type=int, default=0, help="0 = candidate grids when possible, 1 = shadow rays walk the BVH")
     ap.add_argument("--primary-rays", type=int, default=0, help="0 = screen binning, 1 = primary rays walk the BVH")
@@ -165,12 +167,18 @@ def main():
     base = fly.params_copy(row_tile=a.row_tile)
     mine = tiles.part_params(base, world, rank)
     rows = fly.local_rows(mine)
-    stream = torch.cuda.current_stream(dev)
+    # Frames in flight: frame k is enqueued on stream k % F into buffer k % F (the scene keeps one workspace per
+    # stream), so the small, latency-bound launches of one frame overlap the other frames' work.
+    in_flight = max(1, min(a.in_flight, 4 if world == 1 else 2))
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(in_flight - 1)]
+    turn = [0]
     if world == 1:
-        rgb = torch.zeros((max(rows, 1), W, 3), dtype=torch.float32, device=dev)
+        rgbs = [torch.zeros((max(rows, 1), W, 3), dtype=torch.float32, device=dev) for _ in range(in_flight)]
 
         def frame(p):
-            fly.render_device(rgb, params=p, camera=cam, stream=stream)
+            k = turn[0] % in_flight
+            turn[0] += 1
+            fly.render_device(rgbs[k], params=p, camera=cam, stream=streams[k])
 
         def flush():
             pass
@@ -180,9 +188,11 @@ def main():
         pipe = tiles.GatherPipeline(mine, W, 3, dev)
 
         def frame(p):
-            buf = pipe.acquire()
-            fly.render_device(buf, params=p, camera=cam, stream=stream)
-            pipe.submit()
+            k = turn[0] % in_flight
+            turn[0] += 1
+            buf = pipe.acquire(streams[k])
+            fly.render_device(buf, params=p, camera=cam, stream=streams[k])
+            pipe.submit(streams[k])
 
         def flush():
             pipe.drain()
@@ -202,17 +212,27 @@ def main():
     work = fly.stats()
 
     timed = tiles.part_params(base, world, rank)
-    timed.flags = 0 if a.no_kernel_events else L.FLAG_TIME_KERNELS
     for _ in range(a.warmup):
         frame(timed)
     sync()
-    fly.stats()  # drop the warm-up's events
     t0 = time.perf_counter()
     for _ in range(a.steps):
         frame(timed)
     sync()
     elapsed = time.perf_counter() - t0
     st = fly.stats()
+    # ---- the same frame again, one at a time on one stream, with HIP events around every launch: per-kernel
+    # durations for the roofline.  Outside the timed region: the events cost about a tenth of a frame, and with
+    # several frames in flight an event pair would also span the other frames' kernels.
+    if not a.no_kernel_events:
+        evented = tiles.part_params(base, world, rank)
+        evented.flags = L.FLAG_TIME_KERNELS
+        scratch = torch.zeros((max(rows, 1), W, 3), dtype=torch.float32, device=dev)
+        for _ in range(a.steps):
+            fly.render_device(scratch, params=evented, camera=cam, stream=streams[0])
+        torch.cuda.synchronize(dev)
+        st = fly.stats()
+        del scratch
 
     # ---- reduce over ranks: slowest rank's time, all ranks' rays
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -252,7 +272,9 @@ def main():
                 "workload": name, "width": W, "height": H, "triangles": int(info.num_faces), "lights": len(w["lights"]),
                 "samples_per_light": 1 + w["soft_points"], "max_reflections": w["max_reflections"],
                 "rays_per_frame": {"primary": int(rays[0].item()), "shadow": int(rays[1].item()), "bounce": int(rays[2].item())},
-                "parallelism": "row tiles of %d rows round-robin over %d GPU(s), one float32 gather per frame, overlapped with the next frame" % (a.row_tile, world),
+                "parallelism": ("one GPU, no exchange" if world == 1 else
+                                "row tiles of %d rows round-robin over %d GPUs, one float32 gather per frame, overlapped with the next frames" % (a.row_tile, world)),
+                "frames_in_flight": in_flight,
                 "shadow_rays": "per-sample candidate grids (%d face references)" % info.shadow_grid_entries if info.shadow_grid_entries else "BVH walk",
                 "bvh": {"nodes": int(info.num_nodes), "leaves": int(info.num_leaves), "depth": int(info.depth),
                         "build_ms": round(float(info.build_ms), 1),
@@ -319,6 +341,23 @@ def main():
             host_ms = (time.perf_counter() - t0) / 5 * 1e3
             out["host_boundary"] = {"ms_per_frame": round(host_ms, 3), "Mrays_per_s": round(rays_frame / host_ms / 1e3, 1),
                                     "note": "rtamd_render with host output buffers, PCIe download included"}
+        if world > 1:
+            # the whole frame of the SAME workload on this one GPU, no exchange: the single-GPU figure that the
+            # N-GPU value above is to be compared with (the N = 1 default of this script is another workload)
+            whole = tiles.part_params(base, 1, 0)
+            full = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for _ in range(in_flight)]
+
+            def whole_frames(n):
+                for i in range(n):
+                    fly.render_device(full[i % in_flight], params=whole, camera=cam, stream=streams[i % in_flight])
+                torch.cuda.synchronize(dev)
+
+            whole_frames(a.warmup + 1)
+            t0 = time.perf_counter()
+            whole_frames(a.steps)
+            one_ms = (time.perf_counter() - t0) / a.steps * 1e3
+            out["single_gpu_same_workload"] = {"ms_per_step": round(one_ms, 4), "value": round(rays_frame / one_ms / 1e3, 3),
+                                               "speedup": round(one_ms / ms_per_step, 3)}
         if world == 1 and a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(w, cam, a.cpu_seconds)
             out["gpu_over_cpu"] = round(value / max(out["cpu_baseline"]["value"], 1e-9), 1)

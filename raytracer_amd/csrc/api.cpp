@@ -59,7 +59,21 @@ double now_ms() {
 
 struct TimedLaunch {
     hipEvent_t start, stop;
-    int kind; // 0 closest-hit walk, 1 shadow walk, 2 compaction, 3 shading, 4 other, 5 whole frame
+    int kind; // 0 closest-hit walk, 1 shadow walk, 2 compaction, 3 shading, 4 other, 5 whole frame, 6 screen-bin pass
+};
+
+constexpr int kMaxFrameSlots = 4;
+
+// What one frame in flight owns.
+struct FrameSlot {
+    Workspace ws{};
+    void *block = nullptr;
+    size_t bins = 0;              // screen bins the workspace holds
+    hipStream_t stream = nullptr; // the caller's stream the slot serves
+    hipEvent_t done = nullptr;    // recorded behind the slot's most recent frame
+    bool used = false;            // `done` has been recorded at least once
+    uint64_t stamp = 0;           // scene clock at the most recent frame
+    std::vector<hipEvent_t> sync; // events that order the streams of a frame with reflections
 };
 
 } // namespace
@@ -71,9 +85,12 @@ struct rtamd_scene {
     void *d_light_pos = nullptr, *d_samples = nullptr, *d_spheres = nullptr, *d_texels = nullptr, *d_tex_info = nullptr;
     void *d_grid_headers = nullptr, *d_grid_cells = nullptr, *d_grid_entries = nullptr;
     DeviceScene ds{};
-    Workspace ws{};
-    void *ws_block = nullptr;
-    size_t ws_bins = 0; // screen bins the workspace holds
+    // Frames in flight: every stream a caller renders on gets a workspace of its own (up to kMaxFrameSlots, then
+    // the least recently used one is handed on), so frames enqueued on different streams may overlap on the GPU.
+    FrameSlot slots[kMaxFrameSlots];
+    int num_slots = 0;
+    int last_slot = -1; // slot of the most recent frame (what rtamd_render_stats reports)
+    uint64_t clock = 0;
     rtamd_scene_info info{};
     bool bin_primary = true; // screen binning of the primary rays (rtamd_build_params::primary_rays)
     std::vector<rtamd_material> materials;
@@ -91,8 +108,6 @@ struct rtamd_scene {
     // HIP-event pairs of every launch (kind 0..4) and frame (kind 5) since the last stats call
     std::vector<TimedLaunch> events;
     size_t events_used = 0;
-    // events that order the streams of a frame with reflections (see rtamd_render_device)
-    std::vector<hipEvent_t> sync;
 };
 
 namespace {
@@ -107,11 +122,11 @@ int upload(void **dst, const std::vector<T> &src, uint64_t *bytes) {
 }
 
 // `slots` = ray slots of the local image = whole 8x8 tiles (a multiple of 64).
-int ensure_workspace(rtamd_scene *s, size_t slots, size_t bins_needed) {
-    if (s->ws_block && (size_t)s->ws.capacity >= slots && s->ws_bins >= (s->bin_primary ? bins_needed : 0)) return RTAMD_OK;
-    if (s->ws_block) {
-        HIP_TRY(hipFree(s->ws_block));
-        s->ws_block = nullptr;
+int ensure_workspace(rtamd_scene *s, FrameSlot &fs, size_t slots, size_t bins_needed) {
+    if (fs.block && (size_t)fs.ws.capacity >= slots && fs.bins >= (s->bin_primary ? bins_needed : 0)) return RTAMD_OK;
+    if (fs.block) {
+        HIP_TRY(hipFree(fs.block)); // waits for the device: no frame still reads the old block
+        fs.block = nullptr;
     }
     const size_t cap = (slots + 255) & ~(size_t)255; // every plane starts 1 KiB aligned
     const size_t nshadow = (size_t)s->ds.num_lights * (size_t)s->ds.spl;
@@ -123,34 +138,34 @@ int ensure_workspace(rtamd_scene *s, size_t slots, size_t bins_needed) {
     const size_t bins = s->bin_primary ? bins_needed : 0;
     const size_t bin_bytes = s->bin_primary ? 256 + (2 * bins + 512 + bin_capacity) * 4 + (ntris + 1) * 16 : 0;
     const size_t total = head + planes * cap * 4 + 2 * nshadow * cap + bin_bytes;
-    HIP_TRY(hipMalloc(&s->ws_block, total));
-    char *base = (char *)s->ws_block;
-    s->ws.stage = (StageCounters *)base;
-    s->ws.work = (WorkCounters *)(base + 2048);
+    HIP_TRY(hipMalloc(&fs.block, total));
+    char *base = (char *)fs.block;
+    fs.ws.stage = (StageCounters *)base;
+    fs.ws.work = (WorkCounters *)(base + 2048);
     static_assert(sizeof(StageCounters) * kMaxStages <= 2048, "counter block too small");
     char *p = base + head;
-    s->ws.slot_tri = (int32_t *)p, p += cap * 4;
-    s->ws.slot_t = (float *)p, p += cap * 4;
-    for (HitList &h : s->ws.hits) {
+    fs.ws.slot_tri = (int32_t *)p, p += cap * 4;
+    fs.ws.slot_t = (float *)p, p += cap * 4;
+    for (HitList &h : fs.ws.hits) {
         h.slot = (int32_t *)p, p += cap * 4;
         h.tri = (int32_t *)p, p += cap * 4;
         h.child = (int32_t *)p, p += cap * 4;
         h.p = (float *)p, p += 3 * cap * 4;
     }
-    for (float *&q : s->ws.queue) q = (float *)p, p += 10 * cap * 4;
-    for (uint8_t *&c : s->ws.clear) c = (uint8_t *)p, p += nshadow * cap;
-    s->ws.bin_entries = nullptr;
+    for (float *&q : fs.ws.queue) q = (float *)p, p += 10 * cap * 4;
+    for (uint8_t *&c : fs.ws.clear) c = (uint8_t *)p, p += nshadow * cap;
+    fs.ws.bin_entries = nullptr;
     if (s->bin_primary) {
         p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-        s->ws.big = (int4 *)p, p += (ntris + 1) * 16;
-        s->ws.bin_state = (BinState *)p, p += 256;
-        s->ws.bin_count = (int32_t *)p, p += (bins + 256) * 4;
-        s->ws.bin_start = (int32_t *)p, p += (bins + 256) * 4;
-        s->ws.bin_entries = (int32_t *)p, p += bin_capacity * 4;
-        s->ws.bin_capacity = (int32_t)bin_capacity;
-        s->ws_bins = bins;
+        fs.ws.big = (int4 *)p, p += (ntris + 1) * 16;
+        fs.ws.bin_state = (BinState *)p, p += 256;
+        fs.ws.bin_count = (int32_t *)p, p += (bins + 256) * 4;
+        fs.ws.bin_start = (int32_t *)p, p += (bins + 256) * 4;
+        fs.ws.bin_entries = (int32_t *)p, p += bin_capacity * 4;
+        fs.ws.bin_capacity = (int32_t)bin_capacity;
+        fs.bins = bins;
     }
-    s->ws.capacity = (int32_t)cap;
+    fs.ws.capacity = (int32_t)cap;
     return RTAMD_OK;
 }
 
@@ -188,6 +203,32 @@ int side_streams(int device, SideStreams **out) {
         HIP_TRY(hipStreamCreateWithPriority(&ss.deep_shadow, hipStreamNonBlocking, prio));
     }
     *out = &ss;
+    return RTAMD_OK;
+}
+
+// The slot that serves `stream`.  When all slots are taken the least recently used one changes hands, after the
+// host has waited for its last frame: no stream ever waits for another one here.
+int acquire_slot(rtamd_scene *s, hipStream_t stream, FrameSlot **out) {
+    int pick = -1;
+    for (int i = 0; i < s->num_slots; ++i)
+        if (s->slots[i].stream == stream) pick = i;
+    if (pick < 0 && s->num_slots < kMaxFrameSlots) {
+        pick = s->num_slots++;
+        HIP_TRY(hipEventCreateWithFlags(&s->slots[pick].done, hipEventDisableTiming));
+        // the first slot's frames may use the side streams: let them end before a second caller stream joins
+        if (pick == 1 && s->slots[0].used) HIP_TRY(hipEventSynchronize(s->slots[0].done));
+    }
+    if (pick < 0) {
+        pick = 0;
+        for (int i = 1; i < s->num_slots; ++i)
+            if (s->slots[i].stamp < s->slots[pick].stamp) pick = i;
+        if (s->slots[pick].used) HIP_TRY(hipEventSynchronize(s->slots[pick].done));
+    }
+    FrameSlot &fs = s->slots[pick];
+    fs.stream = stream;
+    fs.stamp = ++s->clock;
+    s->last_slot = pick;
+    *out = &fs;
     return RTAMD_OK;
 }
 
@@ -459,14 +500,20 @@ int rtamd_scene_destroy(rtamd_scene *s) {
     if (!s) return RTAMD_OK;
     void *bufs[] = {s->d_nodes, s->d_tris,  s->d_shade,  s->d_materials, s->d_light_pos, s->d_samples,
                     s->d_spheres, s->d_texels, s->d_tex_info, s->d_grid_headers, s->d_grid_cells, s->d_grid_entries,
-                    s->ws_block, s->d_rgb, s->d_face};
+                    s->d_rgb, s->d_face};
+    (void)hipDeviceSynchronize(); // frames may still be in flight on the caller's streams
     for (void *b : bufs)
         if (b) (void)hipFree(b);
+    for (int i = 0; i < s->num_slots; ++i) {
+        FrameSlot &fs = s->slots[i];
+        if (fs.block) (void)hipFree(fs.block);
+        if (fs.done) (void)hipEventDestroy(fs.done);
+        for (hipEvent_t e : fs.sync) (void)hipEventDestroy(e);
+    }
     for (TimedLaunch &t : s->events) {
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
     }
-    for (hipEvent_t e : s->sync) (void)hipEventDestroy(e);
     delete s;
     return RTAMD_OK;
 }
@@ -501,7 +548,10 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     if (slots * (nshadow ? nshadow : 1) > (size_t)0x7f000000)
         return fail(RTAMD_ERR_LIMIT, "%zu ray slots x %zu shadow rays per hit exceed the 2^31 work-item limit of one launch", slots, nshadow);
     const int bins_x = (p->width + kBinPixels - 1) / kBinPixels, bins_y = (p->height + kBinPixels - 1) / kBinPixels;
-    rc = ensure_workspace(s, slots, (size_t)bins_x * (size_t)bins_y);
+    FrameSlot *slot = nullptr;
+    if ((rc = acquire_slot(s, stream, &slot)) != RTAMD_OK) return rc;
+    FrameSlot &fs = *slot;
+    rc = ensure_workspace(s, fs, slots, (size_t)bins_x * (size_t)bins_y);
     if (rc != RTAMD_OK) return rc;
 
     FrameConst fc;
@@ -523,8 +573,9 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     // inverse of camera_direction for the screen binning: r = s * L * (n + e), see project_point in kernels.hip
     // binning pays when the faces are few against the pixels this rank renders: its cost grows with the faces,
     // the tree walk's with the pixels (a tiny image of a huge mesh, or one rank of many, walks the tree)
-    bool bins_ok = s->bin_primary && s->ws.bin_entries != nullptr && bins_x < 32768 && bins_y < 32768 &&
-                   4 * (size_t)s->info.num_device_faces <= pixels;
+    static const double faces_per_pixel_max = getenv("RTAMD_BIN_FACES_PER_PIXEL") ? atof(getenv("RTAMD_BIN_FACES_PER_PIXEL")) : 0.25;
+    bool bins_ok = s->bin_primary && fs.ws.bin_entries != nullptr && bins_x < 32768 && bins_y < 32768 &&
+                   (double)s->info.num_device_faces <= faces_per_pixel_max * (double)pixels;
     if (bins_ok) {
         const float *m = cam->inv_view;
         const double a = m[0], b = m[1], c = m[2], d0 = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
@@ -543,7 +594,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
         }
         fc.bins_x = bins_x, fc.bins_y = bins_y;
     }
-    Workspace ws_frame = s->ws; // what the kernels of this frame see
+    Workspace ws_frame = fs.ws; // what the kernels of this frame see
     if (!bins_ok) ws_frame.bin_entries = nullptr;
     ws_frame.num_bins = bins_x * bins_y;
 
@@ -584,25 +635,28 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     // all shading runs in order.  Buffers rotate (hit lists and shadow results by d & 1, queues by d % 3):
     // compact(d + 2) is the first kernel to overwrite what shade(d) reads, and waits for it.
     static const bool serial = getenv("RTAMD_SERIAL") != nullptr; // experiment hook: everything on the caller's stream
-    const bool two_streams = depths > 1 && !serial && (p->flags & RTAMD_FLAG_SINGLE_STREAM) == 0;
+    // Side streams only for a scene that is rendered on ONE caller stream.  A caller with several streams overlaps
+    // whole frames instead, each entirely on its own stream: the streams in use then outnumber the hardware
+    // queues, and waits between streams that share a queue are what must not happen (see side_streams).
+    const bool two_streams = depths > 1 && !serial && (p->flags & RTAMD_FLAG_SINGLE_STREAM) == 0 && s->num_slots == 1;
     hipStream_t geo = stream, deep = stream;
     if (two_streams) {
         SideStreams *side = nullptr;
         if ((rc = side_streams(s->device, &side)) != RTAMD_OK) return rc;
         geo = side->geometry;
         deep = side->deep_shadow;
-        while (s->sync.size() < (size_t)(3 * depths + 1)) {
+        while (fs.sync.size() < (size_t)(3 * depths + 1)) {
             hipEvent_t e;
             HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            s->sync.push_back(e);
+            fs.sync.push_back(e);
         }
     }
-    auto compacted = [&](int d) { return s->sync[(size_t)(1 + 3 * d)]; };
-    auto shaded = [&](int d) { return s->sync[(size_t)(2 + 3 * d)]; };
-    auto shadowed = [&](int d) { return s->sync[(size_t)(3 + 3 * d)]; };
+    auto compacted = [&](int d) { return fs.sync[(size_t)(1 + 3 * d)]; };
+    auto shaded = [&](int d) { return fs.sync[(size_t)(2 + 3 * d)]; };
+    auto shadowed = [&](int d) { return fs.sync[(size_t)(3 + 3 * d)]; };
     const bool deep_bg = p->background_deep[0] != 0.0f || p->background_deep[1] != 0.0f || p->background_deep[2] != 0.0f;
 
-    HIP_TRY(hipMemsetAsync(s->ws_block, 0, 4096, stream));
+    HIP_TRY(hipMemsetAsync(fs.block, 0, 4096, stream));
     int stage = 0;
     for (int xs = 0; xs < S; ++xs)
         for (int ys = 0; ys < S; ++ys) {
@@ -610,8 +664,8 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
             fc.sub_y = (float)ys / S;
             fc.accumulate = (xs | ys) != 0;
             if (two_streams) { // everything enqueued so far (counters cleared, previous pass shaded) precedes this pass
-                HIP_TRY(hipEventRecord(s->sync[0], stream));
-                HIP_TRY(hipStreamWaitEvent(geo, s->sync[0], 0));
+                HIP_TRY(hipEventRecord(fs.sync[0], stream));
+                HIP_TRY(hipStreamWaitEvent(geo, fs.sync[0], 0));
             }
             for (int d = 0; d < depths; ++d, ++stage) {
                 const bool spawn = d + 1 < depths;
@@ -623,7 +677,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
                 if ((rc = end()) != RTAMD_OK) return rc;
                 if (two_streams && d >= 2) HIP_TRY(hipStreamWaitEvent(geo, shaded(d - 2), 0));
                 if ((rc = begin(2)) != RTAMD_OK) return rc;
-                launch_compact(d == 0, s->ds, fc, s->ws, stage, d, spawn, deep_bg && d > 0, rgb, face_id, t_hit, geo);
+                launch_compact(d == 0, s->ds, fc, fs.ws, stage, d, spawn, deep_bg && d > 0, rgb, face_id, t_hit, geo);
                 if ((rc = end()) != RTAMD_OK) return rc;
                 if (two_streams) HIP_TRY(hipEventRecord(compacted(d), geo));
                 // ---- shadow rays: depth 0 on the caller's stream, deeper ones beside it
@@ -632,7 +686,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
                 if (nshadow > 0) {
                     stream_of_launch = sh;
                     if ((rc = begin(1)) != RTAMD_OK) return rc;
-                    launch_walk_shadow(count, s->ds, fc, s->ws, stage, d, sh);
+                    launch_walk_shadow(count, s->ds, fc, fs.ws, stage, d, sh);
                     if ((rc = end()) != RTAMD_OK) return rc;
                 }
                 if (two_streams && d > 0) {
@@ -642,8 +696,8 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
                 // ---- shading, in depth order
                 stream_of_launch = stream;
                 if ((rc = begin(3)) != RTAMD_OK) return rc;
-                launch_shade(d == 0, s->ds, fc, s->ws, stage, d, spawn, rgb, stream);
-                if (deep_bg && d > 0) launch_misses(fc, s->ws, stage, d, rgb, stream);
+                launch_shade(d == 0, s->ds, fc, fs.ws, stage, d, spawn, rgb, stream);
+                if (deep_bg && d > 0) launch_misses(fc, fs.ws, stage, d, rgb, stream);
                 if ((rc = end()) != RTAMD_OK) return rc;
                 if (two_streams) HIP_TRY(hipEventRecord(shaded(d), stream));
             }
@@ -655,6 +709,8 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
         if ((rc = end()) != RTAMD_OK) return rc;
     }
     if (timed) HIP_TRY(hipEventRecord(s->events[frame_slot].stop, stream));
+    HIP_TRY(hipEventRecord(fs.done, stream));
+    fs.used = true;
     HIP_TRY(hipGetLastError());
 
     s->last = *p;
@@ -670,11 +726,13 @@ int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
     if (!s || !st) return fail(RTAMD_ERR_INVALID, "null scene or stats");
     std::memset(st, 0, sizeof *st);
     if (!s->have_frame) return RTAMD_OK;
-    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    for (int i = 0; i < s->num_slots; ++i) // timing events of every frame in flight must have completed
+        if (s->slots[i].used) HIP_TRY(hipEventSynchronize(s->slots[i].done));
+    const Workspace &ws_last = s->slots[s->last_slot].ws;
     std::vector<StageCounters> sc((size_t)kMaxStages);
     WorkCounters wc[3];
-    HIP_TRY(hipMemcpy(sc.data(), s->ws.stage, sizeof(StageCounters) * kMaxStages, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(wc, s->ws.work, sizeof wc, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sc.data(), ws_last.stage, sizeof(StageCounters) * kMaxStages, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(wc, ws_last.work, sizeof wc, hipMemcpyDeviceToHost));
     st->rays_primary = s->last_primary;
     const uint64_t per_hit = (uint64_t)s->ds.num_lights * (uint64_t)s->ds.spl;
     for (int i = 0; i < s->last_stages; ++i) {

@@ -6,6 +6,7 @@ read-only scene and renders its tiles into a packed buffer.  The only exchange i
 packed buffers to rank 0 (torch.distributed.gather: on the nccl backend, i.e. RCCL, that is one
 grouped send/recv per peer, so the root's xGMI links are used concurrently).
 """
+import contextlib
 import ctypes as C
 
 import torch
@@ -106,7 +107,9 @@ class GatherPipeline:
             image = pipe.submit()         # starts this frame's gather; returns the frame finished by acquire(), if any
         last = pipe.drain()               # list of the frames still in flight, oldest first
 
-    Images are returned on rank `dst` only (None elsewhere) and lag the submissions by up to two frames."""
+    Images are returned on rank `dst` only (None elsewhere) and lag the submissions by up to two frames.
+    acquire() and submit() take the stream the frame is rendered on (default: the current stream), so that two
+    frames may also be TRACED at the same time, each on a stream of its own: buffer k % 2 goes with stream k % 2."""
 
     def __init__(self, params, width, channels, device, dtype=torch.float32, group=None, dst=0):
         self.params, self.group, self.dst = params, group, dst
@@ -138,18 +141,24 @@ class GatherPipeline:
         flat = self.recv[b].view((self.world * self.rows_max,) + tuple(self.send[b].shape[1:]))
         return flat.index_select(0, self.index)
 
-    def acquire(self):
-        self.done = self._finish(self.turn)
+    @staticmethod
+    def _on(stream):
+        return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+
+    def acquire(self, stream=None):
+        with self._on(stream):  # the wait for the buffer's previous gather, and its assembly, go to the frame's stream
+            self.done = self._finish(self.turn)
         return self.send[self.turn]
 
-    def submit(self):
+    def submit(self, stream=None):
         b = self.turn
-        if self.world == 1:
-            self.work[b] = True
-        elif self.rank == self.dst:
-            self.work[b] = dist.gather(self.send[b], list(self.recv[b].unbind(0)), dst=self.dst, group=self.group, async_op=True)
-        else:
-            self.work[b] = dist.gather(self.send[b], None, dst=self.dst, group=self.group, async_op=True)
+        with self._on(stream):  # the collective starts behind what this stream has enqueued
+            if self.world == 1:
+                self.work[b] = True
+            elif self.rank == self.dst:
+                self.work[b] = dist.gather(self.send[b], list(self.recv[b].unbind(0)), dst=self.dst, group=self.group, async_op=True)
+            else:
+                self.work[b] = dist.gather(self.send[b], None, dst=self.dst, group=self.group, async_op=True)
         self.turn ^= 1
         out, self.done = self.done, None
         return out

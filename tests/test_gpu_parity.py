@@ -189,6 +189,41 @@ def test_device_builder_on_a_large_mesh_and_its_fallback():
     assert (one.render()["face_id"] >= 0).any()
 
 
+def test_frames_in_flight_on_several_streams():
+    """Every stream a caller renders on gets a workspace of its own: frames enqueued on different streams may run
+    at the same time and still give the frames a single stream gives, also with more streams than workspaces."""
+    import torch
+
+    fly, _ = make_pair("reflect_test", width=160, height=120)
+    cams = []
+    for k in range(6):
+        fly.camera_translate(0.4, -0.2, 1.0)
+        fly.camera_rotate(0.05, -0.03)
+        cams.append(fly.getCamera())
+    shape = (120, 160)
+    want = []
+    for cam in cams:
+        rgb = torch.zeros(shape + (3,), dtype=torch.float32, device="cuda")
+        fid = torch.zeros(shape, dtype=torch.int32, device="cuda")
+        fly.render_device(rgb, fid, camera=cam)
+        torch.cuda.synchronize()
+        want.append((rgb.cpu().numpy(), fid.cpu().numpy()))
+    assert fly.stats().rays_bounce > 0
+    assert not np.array_equal(want[0][1], want[5][1])
+    for nstreams in (2, 3, 6):  # 6 > the four workspaces a scene keeps: the least recently used one changes hands
+        streams = [torch.cuda.Stream() for _ in range(nstreams)]
+        outs = [(torch.zeros(shape + (3,), dtype=torch.float32, device="cuda"), torch.zeros(shape, dtype=torch.int32, device="cuda"))
+                for _ in cams]
+        torch.cuda.synchronize()
+        for rounds in range(3):
+            for k, cam in enumerate(cams):
+                fly.render_device(outs[k][0], outs[k][1], camera=cam, stream=streams[k % nstreams])
+        torch.cuda.synchronize()
+        for k in range(len(cams)):
+            assert np.array_equal(outs[k][1].cpu().numpy(), want[k][1]), (nstreams, k)
+            assert np.array_equal(outs[k][0].cpu().numpy().view(np.uint32), want[k][0].view(np.uint32)), (nstreams, k)
+
+
 def test_degenerate_sample_direction_falls_back_to_the_tree():
     # a light at the origin gives a zero shadow-ray direction (its hard-shadow sample): no grid can be built for it
     fly, orc = make_pair("glass", width=48, height=48, lights=[(0.0, 0.0, 0.0)], soft_points=0)
