@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--sah-bins", type=int, default=0, help="BVH: SAH bins (0 = library default)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="frames enqueued at a time, each on a stream of its own (1..4; at most 2 with several GPUs)")
+    ap.add_argument("--gather", choices=("u8", "f32"), default="u8",
+                    help="what the ranks send to rank 0: the 8-bit pixels the reference writes to result.ppm, or the float framebuffer")
     ap.add_argument("--builder", type=int, default=0, help="0 = host SAH builder, 1 = on-GPU Morton-order builder")
     ap.add_argument("--shadow-rays", type=int, default=0, help="0 = candidate grids when possible, 1 = shadow rays walk the BVH")
     ap.add_argument("--primary-rays", type=int, default=0, help="0 = screen binning, 1 = primary rays walk the BVH")
@@ -185,13 +187,22 @@ def main():
     else:
         # Two frame buffers: the gather of frame k (RCCL, on its own stream) overlaps the tracing of frame k+1.
         # Every frame is still gathered and put in row order on rank 0 inside the timed region.
-        pipe = tiles.GatherPipeline(mine, W, 3, dev)
+        # What is exchanged is what the reference keeps of a frame: the 8-bit pixels of result.ppm, quantised on
+        # every rank with the file writer's expression (a quarter of the float framebuffer's bytes); --gather f32
+        # sends the floats instead.
+        as_bytes = a.gather == "u8"
+        pipe = tiles.GatherPipeline(mine, W, 3, dev, dtype=torch.uint8 if as_bytes else torch.float32)
+        rgbs = [torch.zeros((max(rows, 1), W, 3), dtype=torch.float32, device=dev) for _ in range(in_flight)] if as_bytes else None
 
         def frame(p):
             k = turn[0] % in_flight
             turn[0] += 1
             buf = pipe.acquire(streams[k])
-            fly.render_device(buf, params=p, camera=cam, stream=streams[k])
+            if as_bytes:
+                fly.render_device(rgbs[k], params=p, camera=cam, stream=streams[k])
+                tiles.quantize_ppm(rgbs[k], buf, rows * W * 3, stream=streams[k])
+            else:
+                fly.render_device(buf, params=p, camera=cam, stream=streams[k])
             pipe.submit(streams[k])
 
         def flush():
@@ -273,7 +284,8 @@ def main():
                 "samples_per_light": 1 + w["soft_points"], "max_reflections": w["max_reflections"],
                 "rays_per_frame": {"primary": int(rays[0].item()), "shadow": int(rays[1].item()), "bounce": int(rays[2].item())},
                 "parallelism": ("one GPU, no exchange" if world == 1 else
-                                "row tiles of %d rows round-robin over %d GPUs, one float32 gather per frame, overlapped with the next frames" % (a.row_tile, world)),
+                                "row tiles of %d rows round-robin over %d GPUs, one %s gather per frame, overlapped with the next frames" %
+                                (a.row_tile, world, "8-bit (PPM pixels)" if a.gather == "u8" else "float32")),
                 "frames_in_flight": in_flight,
                 "shadow_rays": "per-sample candidate grids (%d face references)" % info.shadow_grid_entries if info.shadow_grid_entries else "BVH walk",
                 "bvh": {"nodes": int(info.num_nodes), "leaves": int(info.num_leaves), "depth": int(info.depth),

@@ -227,9 +227,16 @@ int rtamd_render_device(rtamd_scene *scene, const rtamd_camera *cam, const rtamd
                         int32_t *face_id_dev, float *t_hit_dev, void *hip_stream);
 int rtamd_render_stats(rtamd_scene *scene, rtamd_stats *stats);
 
+/* The 8-bit image writePPMImage stores (utils/ppmIO.hpp:188-209): bytes_dev[i] = min(255, (int)(255 *
+ * rgb_dev[i])) for `count` channel values, on the device and on hip_stream.  With several GPUs the ranks
+ * can exchange these bytes instead of the floats: a quarter of the traffic, the same result.ppm.
+ * rgb_dev 16-byte aligned, bytes_dev 4-byte aligned. */
+int rtamd_quantize_ppm(const float *rgb_dev, uint8_t *bytes_dev, uint64_t count, void *hip_stream);
+
 /* Interleave the packed rows of `num_parts` parts (as gathered on one device, part-major) back
  * into image order.  src_dev = concatenation over parts of local_rows(part)*width*channels
- * elements of 4 bytes; dst_dev = height*width*channels.  Enqueued on hip_stream. */
+ * elements of 4 bytes; dst_dev = height*width*channels.  Enqueued on hip_stream.  (Rows of 8-bit
+ * pixels: pass width*3/4 as width with channels = 1 when width*3 is a multiple of 4.) */
 int rtamd_assemble_rows(const rtamd_render_params *p, const void *src_dev, void *dst_dev, int32_t channels,
                         void *hip_stream);
 

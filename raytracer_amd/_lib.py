@@ -112,6 +112,7 @@ SYMBOLS = {
     "rtamd_render": (C.c_int, [_P, C.POINTER(Camera), C.POINTER(RenderParams), _fp, _ip, C.POINTER(Stats)]),
     "rtamd_render_device": (C.c_int, [_P, C.POINTER(Camera), C.POINTER(RenderParams), _P, _P, _P, _P]),
     "rtamd_render_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "rtamd_quantize_ppm": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "rtamd_assemble_rows": (C.c_int, [C.POINTER(RenderParams), _P, _P, C.c_int32, _P]),
     "rtfly_create": (C.c_int, [C.POINTER(_P)]),
     "rtfly_destroy": (C.c_int, [_P]),

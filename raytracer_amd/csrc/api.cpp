@@ -571,9 +571,10 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     std::memcpy(fc.bg_deep, p->background_deep, sizeof fc.bg_deep);
 
     // inverse of camera_direction for the screen binning: r = s * L * (n + e), see project_point in kernels.hip
-    // binning pays when the faces are few against the pixels this rank renders: its cost grows with the faces,
-    // the tree walk's with the pixels (a tiny image of a huge mesh, or one rank of many, walks the tree)
-    static const double faces_per_pixel_max = getenv("RTAMD_BIN_FACES_PER_PIXEL") ? atof(getenv("RTAMD_BIN_FACES_PER_PIXEL")) : 0.25;
+    // binning pays unless the faces are many against the pixels this rank renders: its cost grows with the faces,
+    // the tree walk's with the pixels.  Measured on a 1.1 M-face field: still ahead at one face per pixel (one
+    // rank of eight at 4K), behind at 7.5 faces per pixel (a 256x144 image of 278 K faces).
+    static const double faces_per_pixel_max = getenv("RTAMD_BIN_FACES_PER_PIXEL") ? atof(getenv("RTAMD_BIN_FACES_PER_PIXEL")) : 2.0;
     bool bins_ok = s->bin_primary && fs.ws.bin_entries != nullptr && bins_x < 32768 && bins_y < 32768 &&
                    (double)s->info.num_device_faces <= faces_per_pixel_max * (double)pixels;
     if (bins_ok) {
@@ -782,6 +783,15 @@ int rtamd_render(rtamd_scene *s, const rtamd_camera *cam, const rtamd_render_par
     HIP_TRY(hipMemcpy(rgb, s->d_rgb, pixels * 12, hipMemcpyDeviceToHost));
     if (face_id) HIP_TRY(hipMemcpy(face_id, s->d_face, pixels * 4, hipMemcpyDeviceToHost));
     if (stats) return rtamd_render_stats(s, stats);
+    return RTAMD_OK;
+}
+
+int rtamd_quantize_ppm(const float *rgb_dev, uint8_t *bytes_dev, uint64_t count, void *hip_stream) {
+    if (count == 0) return RTAMD_OK;
+    if (!rgb_dev || !bytes_dev) return fail(RTAMD_ERR_INVALID, "null argument");
+    if (((uintptr_t)rgb_dev & 15) != 0 || ((uintptr_t)bytes_dev & 3) != 0) return fail(RTAMD_ERR_INVALID, "rgb must be 16-byte aligned, bytes 4-byte aligned");
+    launch_quantize(rgb_dev, bytes_dev, (size_t)count, (hipStream_t)hip_stream);
+    HIP_TRY(hipGetLastError());
     return RTAMD_OK;
 }
 

@@ -21,6 +21,7 @@ void launch_shade(bool primary, const DeviceScene &sc, const FrameConst &fc, con
                   hipStream_t stream);
 void launch_misses(const FrameConst &fc, const Workspace &ws, int stage, int depth, float *rgb, hipStream_t stream);
 void launch_scale(float *rgb, size_t n, float divisor, hipStream_t stream);
+void launch_quantize(const float *rgb, uint8_t *out, size_t n, hipStream_t stream);
 void launch_assemble(const void *src, void *dst, int width, int height, int channels, int row_tile, int num_parts, hipStream_t stream);
 
 } // namespace rtamd

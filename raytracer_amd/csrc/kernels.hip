@@ -1066,6 +1066,24 @@ __global__ void scale_kernel(float *rgb, size_t n, float divisor) {
     if (i < n) rgb[i] = rgb[i] / divisor;
 }
 
+// The bytes writePPMImage puts in the file: min(255, (int)(255 * c)) per channel (utils/ppmIO.hpp:203).  Four
+// channels per thread, one 4-byte store; n4 = number of whole groups of four, the tail goes one by one.
+__device__ __forceinline__ unsigned ppm_byte(float c) {
+    const float v = 255.0f * c;
+    // (int) of a value outside the int range is undefined in C; the device conversion saturates, NaN gives 0
+    const int i = (int)v;
+    return (unsigned)max(0, min(255, i)); // the host writer clamps below as well
+}
+__global__ void quantize_kernel(const float *rgb, uint8_t *out, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 4 <= n) {
+        const float4 v = *(const float4 *)(rgb + i);
+        *(unsigned *)(out + i) = ppm_byte(v.x) | (ppm_byte(v.y) << 8) | (ppm_byte(v.z) << 16) | (ppm_byte(v.w) << 24);
+    } else {
+        for (size_t k = i; k < n; ++k) out[k] = (uint8_t)ppm_byte(rgb[k]);
+    }
+}
+
 // Packed part-major rows -> image rows (4-byte elements).
 __global__ void assemble_kernel(const uint32_t *src, uint32_t *dst, int width, int height, int channels, int row_tile, int num_parts) {
     const size_t row_elems = (size_t)width * channels;
@@ -1194,6 +1212,12 @@ void launch_misses(const FrameConst &fc, const Workspace &ws, int stage, int dep
 void launch_scale(float *rgb, size_t n, float divisor, hipStream_t stream) {
     if (n == 0) return;
     scale_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(rgb, n, divisor);
+}
+
+void launch_quantize(const float *rgb, uint8_t *out, size_t n, hipStream_t stream) {
+    if (n == 0) return;
+    const size_t threads = (n + 3) / 4;
+    quantize_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, stream>>>(rgb, out, n);
 }
 
 void launch_assemble(const void *src, void *dst, int width, int height, int channels, int row_tile, int num_parts, hipStream_t stream) {

@@ -29,6 +29,20 @@ def local_rows(params, world, rank):
     return L.lib().rtamd_local_rows(C.byref(part_params(params, world, rank)))
 
 
+def quantize_ppm(rgb, out, count=None, stream=None):
+    """out[i] = min(255, int(255 * rgb[i])) on the device: the bytes the reference's writePPMImage stores
+    (utils/ppmIO.hpp:203).  rgb: float32 CUDA tensor, out: uint8 CUDA tensor, both contiguous."""
+    n = rgb.numel() if count is None else int(count)
+    if rgb.dtype != torch.float32 or out.dtype != torch.uint8 or not rgb.is_cuda or not out.is_cuda:
+        raise ValueError("quantize_ppm wants a float32 and a uint8 CUDA tensor")
+    if not rgb.is_contiguous() or not out.is_contiguous() or rgb.numel() < n or out.numel() < n:
+        raise ValueError("quantize_ppm wants contiguous tensors of at least %d elements" % n)
+    s = stream if stream is not None else torch.cuda.current_stream(rgb.device)
+    L.check(L.lib().rtamd_quantize_ppm(C.c_void_p(rgb.data_ptr()), C.c_void_p(out.data_ptr()), C.c_uint64(n), C.c_void_p(s.cuda_stream)),
+            "rtamd_quantize_ppm")
+    return out
+
+
 _layout_cache = {}
 
 

@@ -361,6 +361,35 @@ def test_row_tile_parts_assemble_to_the_full_frame(parts, tile):
     assert np.array_equal(ids.cpu().numpy(), full["face_id"])
 
 
+def test_device_ppm_quantisation_matches_the_file_writer(tmp_path):
+    """rtamd_quantize_ppm gives the bytes of the reference's writePPMImage (utils/ppmIO.hpp:203), also at channel
+    values of exactly k/255, above 1, and for lengths that are no multiple of four."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    vals = np.concatenate([rng.random(100003, dtype=np.float32) * 1.2, (np.arange(256) / 255.0).astype(np.float32),
+                           np.array([0.0, 1.0, 1.0000001, 0.99999994, 3.5, 1e-30], np.float32)]).astype(np.float32)
+    want = np.minimum(255, (np.float32(255) * vals).astype(np.int32)).astype(np.uint8)
+    for n in (len(vals), 1, 2, 3, 1001):
+        src = torch.from_numpy(vals[:n].copy()).cuda()
+        out = torch.zeros(n + 8, dtype=torch.uint8, device="cuda")
+        tiles.quantize_ppm(src, out, n)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:n], want[:n]) and not got[n:].any()
+    # and the frame a Flyscene writes as P6 holds exactly these bytes
+    fly, _ = make_pair("toy", width=64, height=48)
+    frame = fly.render()["rgb"]
+    path = str(tmp_path / "frame.p6.ppm")
+    from raytracer_amd.flyscene import write_ppm
+
+    write_ppm(path, frame, binary=True)
+    payload = np.frombuffer(open(path, "rb").read()[-64 * 48 * 3:], np.uint8)
+    dev = torch.zeros(64 * 48 * 3, dtype=torch.uint8, device="cuda")
+    tiles.quantize_ppm(torch.from_numpy(frame).cuda(), dev)
+    assert np.array_equal(dev.cpu().numpy(), payload)
+
+
 def test_bvh_leaf_size_does_not_change_the_image():
     a = R.Flyscene(model=scene_path("toy"), output="", max_leaf_faces=1).initialize(96, 96).render()
     b = R.Flyscene(model=scene_path("toy"), output="", max_leaf_faces=8, sah_bins=8).initialize(96, 96).render()

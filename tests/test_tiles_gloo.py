@@ -74,7 +74,7 @@ def test_single_process_path_is_identity():
     assert sorted(idx.tolist()) == list(range(10))
 
 
-def _pipeline_worker(rank, world, port, width, height, tile, frames, q):
+def _pipeline_worker(rank, world, port, width, height, tile, frames, q, dtype=torch.float32):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -83,7 +83,7 @@ def _pipeline_worker(rank, world, port, width, height, tile, frames, q):
         mine = tiles.part_params(base, world, rank)
         lib = L.lib()
         rows = lib.rtamd_local_rows(C.byref(mine))
-        pipe = tiles.GatherPipeline(mine, width, 3, "cpu")
+        pipe = tiles.GatherPipeline(mine, width, 3, "cpu", dtype=dtype)
         got = []
         for k in range(frames):
             buf = pipe.acquire()
@@ -104,13 +104,15 @@ def _pipeline_worker(rank, world, port, width, height, tile, frames, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,height,tile,frames", [(2, 37, 8, 5), (3, 50, 4, 1), (2, 16, 16, 2)])
-def test_double_buffered_gather_returns_every_frame_in_order(world, height, tile, frames):
+@pytest.mark.parametrize("world,height,tile,frames,dtype", [(2, 37, 8, 5, torch.float32), (3, 50, 4, 1, torch.float32),
+                                                            (2, 16, 16, 2, torch.float32), (2, 37, 8, 4, torch.uint8)])
+def test_double_buffered_gather_returns_every_frame_in_order(world, height, tile, frames, dtype):
+    """Also with 8-bit pixels, which is what the ranks exchange by default (the bytes of result.ppm)."""
     width = 8
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, width, height, tile, frames, q)) for r in range(world)]
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, width, height, tile, frames, q, dtype)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)
