@@ -461,6 +461,40 @@ def test_config2_bunny_1080p_bounce_rows_sample():
     _rows_sample_parity("bunny_1080p", 40)
 
 
+def test_config3_bunny_4k_two_lights_hard_shadows_rows_sample():
+    _rows_sample_parity("bunny_4k", 90)
+
+
+def test_config3_subdivided_bunny_1m_faces_4k_rows_sample():
+    # 1.1 M faces in ONE object (config 3's upper end): every face smaller than a pixel
+    _rows_sample_parity("bunny_sub2_4k", 180)
+
+
+def test_config5_mirror_field_8k_rows_sample_and_partition():
+    """Mirrors + 8 lights, depth-4 reflections at 7680x4320: a 1/360 sample of rows against the oracle, ray
+    bookkeeping, and the frame rendered as 8 row-tile parts equals the single-part frame bit for bit."""
+    import torch
+
+    fly, rgb, fid = _rows_sample_parity("field_mirrors_8k", 360)
+    st = fly.stats()
+    assert st.rays_bounce > 10 ** 6
+    w = workloads.get("field_mirrors_8k")
+    cam = workloads.look_at(w["camera"]["eye"], w["camera"]["target"], w["width"], w["height"])
+    base = fly.params_copy(row_tile=16)
+    index = tiles.row_permutation(base, 8, "cuda")
+    offset = 0
+    for part in range(8):
+        p = tiles.part_params(base, 8, part)
+        rows = fly.local_rows(p)
+        buf = torch.zeros((rows, w["width"], 3), dtype=torch.float32, device="cuda")
+        fly.render_device(buf, params=p, camera=cam)
+        torch.cuda.synchronize()
+        mine = (index >= offset) & (index < offset + rows)  # image rows this part owns, in its packed order
+        assert torch.equal(buf, rgb[mine]), part
+        offset += rows
+        del buf
+
+
 def test_config4_like_field_small_full_parity():
     w = workloads.get("field2_small")
     fly, params, cam = workloads.make_flyscene(w)
