@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round-end evidence for profiles/: run on the GPU box from the repository root.
+#   tools/collect_profiles.sh TAG      -> gpurun_out/profiles_TAG/
+set -u
+TAG=${1:-r1}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/profiles_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+# 1. the default bench line, and the other single-GPU workloads
+for wl in bunny_1080p bunny_1000 field_4k; do
+  timeout -k 10 300 python3 "$ROOT/bench.py" --workload $wl $([ $wl = bunny_1080p ] || echo --cpu-seconds 0) 2>/dev/null | tail -1 > "$OUT/bench_$wl.json" || exit 1
+done
+# 2. kernel trace of the default command (two frames in flight: kernels of different frames overlap) ...
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -- \
+  python3 "$ROOT/bench.py" --cpu-seconds 0 > "$OUT/bench_under_rocprof_default.json" 2> "$OUT/trace_default.log" || exit 1
+# 3. ... and with every kernel alone on the GPU: these averages are the ones the roofline's avg_launch_ms must match
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_serial" -- \
+  python3 "$ROOT/bench.py" --cpu-seconds 0 --in-flight 1 --single-stream > "$OUT/bench_under_rocprof_serial.json" 2> "$OUT/trace_serial.log" || exit 1
+cd "$ROOT"
+# 4. hardware counters, one pass per rocprofv3 run
+bash tools/pmc_passes.sh gpurun_out/profiles_$TAG/pmc bunny_1080p || exit 1
+python3 tools/pmc_summary.py gpurun_out/profiles_$TAG/pmc/* > "$OUT/pmc_bunny_1080p.txt"
+find "$OUT" -name "*kernel_stats.csv"

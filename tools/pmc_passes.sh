@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   local name=$1; shift
   timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$ROOT/$OUT/$name" -- \
-    python3 "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-seconds 0 --no-kernel-events --workload "$WL" > "$ROOT/$OUT/$name.log" 2>&1 \
+    python3 "$ROOT/bench.py" --steps 3 --warmup 1 --cpu-seconds 0 --no-kernel-events --in-flight 1 --single-stream --workload "$WL" > "$ROOT/$OUT/$name.log" 2>&1 \
     || { echo "pass $name failed"; tail -3 "$ROOT/$OUT/$name.log"; return 1; }
   echo "pass $name ok"
 }

@@ -9,7 +9,8 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("walk_kernel", "shadow_grid_kernel", "compact_kernel", "trace_kernel", "shade_kernel"):
+    for key in ("walk_kernel", "shadow_grid_kernel", "raster_kernel", "bin_count_kernel", "bin_fill_kernel", "bin_offsets_kernel", "compact_kernel",
+                "shade_kernel"):
         if key in name:
             args = name.split(key)[1].split("(")[0]
             return key + args
