@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--sah-bins", type=int, default=0, help="BVH: SAH bins (0 = library default)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="frames enqueued at a time, each on a stream of its own (1..4; at most 2 with several GPUs)")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="keep every frame on its caller's stream (no side streams): with --in-flight 1 every kernel then runs alone, "
+                         "which is the mode the per-kernel profile under profiles/ is taken in")
     ap.add_argument("--gather", choices=("u8", "f32"), default="u8",
                     help="what the ranks send to rank 0: the 8-bit pixels the reference writes to result.ppm, or the float framebuffer")
     ap.add_argument("--builder", type=int, default=0, help="0 = host SAH builder, 1 = on-GPU Morton-order builder")
@@ -216,13 +219,14 @@ def main():
 
     # ---- instrumented frame (untimed): algorithmic work of each kernel
     counted = tiles.part_params(base, world, rank)
-    counted.flags = L.FLAG_COUNT_WORK
+    counted.flags = L.FLAG_COUNT_WORK | (L.FLAG_SINGLE_STREAM if a.single_stream else 0)
     frame(counted)
     flush()
     torch.cuda.synchronize(dev)
     work = fly.stats()
 
     timed = tiles.part_params(base, world, rank)
+    timed.flags = L.FLAG_SINGLE_STREAM if a.single_stream else 0
     for _ in range(a.warmup):
         frame(timed)
     sync()
@@ -237,7 +241,7 @@ def main():
     # several frames in flight an event pair would also span the other frames' kernels.
     if not a.no_kernel_events:
         evented = tiles.part_params(base, world, rank)
-        evented.flags = L.FLAG_TIME_KERNELS
+        evented.flags = L.FLAG_TIME_KERNELS | L.FLAG_SINGLE_STREAM  # every kernel alone on the GPU
         scratch = torch.zeros((max(rows, 1), W, 3), dtype=torch.float32, device=dev)
         for _ in range(a.steps):
             fly.render_device(scratch, params=evented, camera=cam, stream=streams[0])
