@@ -1113,12 +1113,16 @@ __global__ void assemble_kernel(const uint32_t *src, uint32_t *dst, int width, i
 // ---------------------------------------------------------------------------------------------
 namespace {
 // Worst-case grid of one-wave workgroups, capped (surplus groups are then dealt round-robin) and kept a
-// multiple of 8 so that a wave's XCD family does not change between its round-robin trips.
+// multiple of 8 so that a wave's XCD family does not change between its round-robin trips.  The grid must
+// cover the worst case because the ray count is only known on the device; most of it usually finds nothing
+// to do, and launching an idle workgroup is not free: 421 K of them (1080p x 13 samples) cost about 90 us,
+// as much as the shadow rays of the frame's 160 K hits themselves.  2^17 keeps sixteen rounds of work per
+// wave slot for the balance of large launches.
 int walk_grid(long long groups) {
     static const long long cap = [] { // experiment hook
         const char *e = getenv("RTAMD_WALK_MAX_BLOCKS");
         const long long n = e ? atoll(e) : 0;
-        return n >= 8 ? n : (1ll << 20);
+        return n >= 8 ? n : (1ll << 17);
     }();
     long long b = groups < cap ? groups : cap;
     b = (b + 7) & ~7ll;
