@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--row-tile", type=int, default=16)
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH: faces per leaf (0 = library default)")
     ap.add_argument("--sah-bins", type=int, default=0, help="BVH: SAH bins (0 = library default)")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="frames enqueued at a time, each on a stream of its own (1..4; at most 2 with several GPUs)")
     ap.add_argument("--single-stream", action="store_true",
                     help="keep every frame on its caller's stream (no side streams): with --in-flight 1 every kernel then runs alone, "
