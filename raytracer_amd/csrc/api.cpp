@@ -197,8 +197,8 @@ int side_streams(int device, SideStreams **out) {
     if (!ss.geometry) {
         int least = 0, greatest = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        static const bool flat = getenv("RTAMD_FLAT_PRIORITY") != nullptr; // experiment hook
-        const int prio = flat ? least : greatest;
+        (void)least;
+        const int prio = greatest;
         HIP_TRY(hipStreamCreateWithPriority(&ss.geometry, hipStreamNonBlocking, prio));
         HIP_TRY(hipStreamCreateWithPriority(&ss.deep_shadow, hipStreamNonBlocking, prio));
     }
