@@ -224,6 +224,56 @@ def test_frames_in_flight_on_several_streams():
             assert np.array_equal(outs[k][0].cpu().numpy().view(np.uint32), want[k][0].view(np.uint32)), (nstreams, k)
 
 
+def _random_soup(seed):
+    """Triangle soup with the cases that decide ties and rejections: coincident faces with different materials
+    (the reference keeps the one it meets last), overlapping coplanar faces, zero-area faces, axis-aligned
+    faces (rays inside a face's plane), reflective and dull materials."""
+    rng = np.random.default_rng(seed)
+    n = [1, 2, 7, 40, 300, 2500, 9000, 64][seed % 8]
+    centres = rng.uniform(-1.0, 1.0, (n, 1, 3))
+    size = [1.5, 1.0, 0.8, 0.5, 0.25, 0.08, 0.05, 0.6][seed % 8]
+    tri = (centres + rng.uniform(-size, size, (n, 3, 3))).astype(np.float32)
+    k = max(1, n // 8)
+    tri[:k, :, 2] = np.float32(0.25)                      # axis-aligned, coplanar, overlapping
+    if n >= 4:
+        tri[k:2 * k] = tri[:k]                            # coincident copies (other materials below)
+        tri[2 * k] = tri[2 * k][[0, 0, 1]]                # zero area
+        tri[2 * k + 1 if 2 * k + 1 < n else 0, :, 0] = np.float32(-0.3)
+    verts = tri.reshape(-1, 3)
+    faces = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    nmat = 4
+    mats = []
+    for m in range(nmat):
+        ks = float(rng.choice([0.0, 0.1, 0.3, 0.9]))
+        mats.append(dict(ka=rng.uniform(0, 0.2, 3).tolist(), kd=rng.uniform(0.1, 1.0, 3).tolist(), ks=[ks] * 3,
+                         shininess=float(rng.choice([1.0, 8.0, 64.0]))))
+    fmat = rng.integers(0, nmat, n).astype(np.int32)
+    lights = [tuple(rng.uniform(-2.0, 2.0, 3).tolist()) for _ in range(1 + seed % 3)]
+    return (verts, None, faces, fmat, mats), lights
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_triangle_soups_every_path(seed):
+    """Random soups through (a) the default path (screen bins, shadow grids, host SAH tree), (b) the tree for every
+    ray, (c) the device-built tree: each against the oracle, and all three bit-identical to each other."""
+    arrays, lights = _random_soup(seed)
+    kw = dict(arrays=arrays, lights=lights, soft_points=seed % 4, width=72, height=56)
+    fly, orc = make_pair(**kw)
+    r = compare(fly, orc, 72, 56, max_reflections=3)
+    assert_parity(r)
+    base = r["got"]
+    for build in (dict(primary_rays=L.PRIMARY_RAYS_TREE, shadow_rays=L.SHADOW_RAYS_TREE),
+                  dict(builder=L.BUILDER_DEVICE_LBVH, primary_rays=L.PRIMARY_RAYS_TREE, shadow_rays=L.SHADOW_RAYS_TREE),
+                  dict(builder=L.BUILDER_DEVICE_LBVH, max_leaf_faces=1)):
+        other = R.Flyscene(arrays=arrays, lights=lights, soft_points=seed % 4, output="", **build).initialize(72, 56)
+        other.set_params(max_reflections=3)
+        got = other.render()
+        assert np.array_equal(got["face_id"], base["face_id"]), build
+        assert np.array_equal(got["rgb"].view(np.uint32), base["rgb"].view(np.uint32)), build
+        so, sb = got["stats"], base["stats"]
+        assert (so.rays_shadow, so.rays_bounce, so.hits) == (sb.rays_shadow, sb.rays_bounce, sb.hits), build
+
+
 def test_degenerate_sample_direction_falls_back_to_the_tree():
     # a light at the origin gives a zero shadow-ray direction (its hard-shadow sample): no grid can be built for it
     fly, orc = make_pair("glass", width=48, height=48, lights=[(0.0, 0.0, 0.0)], soft_points=0)
