@@ -316,20 +316,24 @@ def main():
             per_launch_ms = group_ms[k] / group_launches[k]
             flops_launch = flops[k] / launches_per_frame
             bytes_launch = byts[k] / launches_per_frame
-            ach = flops_launch / (per_launch_ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": kname, "bound": "valu", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None,
-                               "avg_launch_ms": round(per_launch_ms, 4), "launches_per_frame": launches_per_frame,
-                               "share_of_frame": round(group_ms[k] / max(kmax[6].item(), 1e-9), 3)}
+            # Two rooflines of that kernel, both from its ALGORITHMIC work per launch (counted tests x bytes or flops per
+            # test) over its average launch duration.  `roofline` is the memory one the bench contract names; the path
+            # is bound by neither (dependent fetches of small records, divergent FP32 VALU work), which is why both
+            # fractions are far from 1 and why `traffic`, the bytes that really reached HBM, is below the algorithmic
+            # bytes: the caches serve the re-reads.
+            ach_b = bytes_launch / (per_launch_ms * 1e-3) / 1e9
             traffic, traffic_src = pmc_traffic(name, (closest_key, shadow_key, "raster_kernel<false>")[k])
-            out["roofline"]["traffic"] = None if traffic is None else round(traffic)
+            out["roofline"] = {"kernel": kname, "bound": "hbm", "achieved": round(ach_b, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": round(ach_b / PEAK_HBM_GBS, 4), "traffic": None if traffic is None else round(traffic),
+                               "algorithmic_bytes_per_launch": round(bytes_launch),
+                               "avg_launch_ms": round(per_launch_ms, 4), "launches_per_frame": launches_per_frame,
+                               "share_of_frame": round(group_ms[k] / max(kmax[6].item(), 1e-9), 3),
+                               "note": "algorithmic bytes are mostly served by L2 / Infinity Cache; the scene is %.1f MB" % (info.device_bytes / 1e6)}
             if traffic is not None:
                 out["roofline"]["traffic_unit"] = "bytes/launch at the L2's memory side, (2*FETCH_SIZE + WRITE_SIZE) KiB, from profiles/" + traffic_src
-                out["roofline"]["algorithmic_bytes_per_launch"] = round(bytes_launch)
-            ach_b = bytes_launch / (per_launch_ms * 1e-3) / 1e9
-            out["roofline_hbm"] = {"kernel": kname, "bound": "hbm", "achieved": round(ach_b, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": round(ach_b / PEAK_HBM_GBS, 4), "traffic": None if traffic is None else round(traffic),
-                                   "note": "algorithmic bytes are served by L2 / Infinity Cache; the scene is %.1f MB" % (info.device_bytes / 1e6)}
+            ach = flops_launch / (per_launch_ms * 1e-3) / 1e12
+            out["roofline_valu"] = {"kernel": kname, "bound": "valu", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(ach / PEAK_FP32_TFLOPS, 4), "algorithmic_flops_per_launch": round(flops_launch)}
             out["kernels"] = {"trace_ms_per_frame": round(group_ms[0] / a.steps, 4), "shadow_ms_per_frame": round(group_ms[1] / a.steps, 4),
                               "raster_ms_per_frame": round(group_ms[2] / a.steps, 4),
                               "compact_ms_per_frame": round(kmax[4].item() / a.steps, 4), "shade_ms_per_frame": round(kmax[5].item() / a.steps, 4),
