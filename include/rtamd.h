@@ -84,8 +84,11 @@ typedef struct {
     int32_t num_textures;
 } rtamd_scene_desc;
 
-#define RTAMD_PRIMARY_RAYS_AUTO 0 /* per-pass screen binning of the faces (all primary rays share the eye) */
+#define RTAMD_PRIMARY_RAYS_AUTO 0 /* per-pass screen binning of the faces (all primary rays share the eye),
+                                     the BVH where that is cheaper                                          */
 #define RTAMD_PRIMARY_RAYS_TREE 1 /* primary rays walk the BVH like bounce rays                            */
+#define RTAMD_PRIMARY_RAYS_BINS 2 /* screen binning whenever it is possible, also where AUTO would walk the
+                                     tree because the bins' lists come out long (small image, dense mesh)   */
 #define RTAMD_SHADOW_RAYS_AUTO 0 /* per-sample candidate grids when every sample direction allows it   */
 #define RTAMD_SHADOW_RAYS_TREE 1 /* shadow rays walk the BVH like every other ray                       */
 
@@ -164,6 +167,12 @@ typedef struct {
     int32_t frames;
     float ms_raster;       /* screen-bin pass: bin count, offsets, fill and raster kernels        */
     int32_t launches_raster; /* passes, not kernels                                               */
+    /* Last pass of the most recent frame, when it binned its faces (0 otherwise): */
+    uint32_t bin_entries;    /* face references in the screen bins                                */
+    uint32_t bins_nonempty;  /* bins holding at least one face                                    */
+    int32_t primary_path;    /* 1: primary rays were resolved through the bins, 0: by the BVH walk
+                              * (no binning, bin buffer too small, or lists too long to pay)      */
+    int32_t reserved;
 } rtamd_stats;
 
 typedef struct {

@@ -11,7 +11,7 @@ OK, ERR_INVALID, ERR_HIP, ERR_LIMIT, ERR_NO_DEVICE = 0, 1, 2, 3, 4
 FACE_SPHERE, FACE_MISS = -1, -2
 FLAG_COUNT_WORK, FLAG_TIME_KERNELS, FLAG_SINGLE_STREAM = 1, 2, 4
 SHADOW_RAYS_AUTO, SHADOW_RAYS_TREE = 0, 1
-PRIMARY_RAYS_AUTO, PRIMARY_RAYS_TREE = 0, 1
+PRIMARY_RAYS_AUTO, PRIMARY_RAYS_TREE, PRIMARY_RAYS_BINS = 0, 1, 2
 BUILDER_HOST_SAH, BUILDER_DEVICE_LBVH = 0, 1
 
 
@@ -70,6 +70,7 @@ class Stats(C.Structure):
         ("ms_trace", C.c_float), ("ms_shadow", C.c_float), ("ms_compact", C.c_float), ("ms_shade", C.c_float),
         ("ms_frames", C.c_float), ("launches_trace", C.c_int32), ("launches_shadow", C.c_int32), ("frames", C.c_int32),
         ("ms_raster", C.c_float), ("launches_raster", C.c_int32),
+        ("bin_entries", C.c_uint32), ("bins_nonempty", C.c_uint32), ("primary_path", C.c_int32), ("reserved", C.c_int32),
     ]
 
     @property

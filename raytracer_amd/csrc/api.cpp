@@ -73,6 +73,12 @@ struct FrameSlot {
     hipEvent_t done = nullptr;    // recorded behind the slot's most recent frame
     bool used = false;            // `done` has been recorded at least once
     uint64_t stamp = 0;           // scene clock at the most recent frame
+    bool binned = false;          // the most recent frame ran the screen-bin passes
+    // What the binning passes of earlier frames on this slot reported (pinned host memory the kernels write):
+    // while it says that the lists were too long, the next frames of the same view walk the tree right away.
+    volatile int32_t *feedback = nullptr;
+    uint64_t feedback_key = 0;    // image size and partition the report belongs to
+    int frames_without_bins = 0;
     std::vector<hipEvent_t> sync; // events that order the streams of a frame with reflections
 };
 
@@ -93,6 +99,7 @@ struct rtamd_scene {
     uint64_t clock = 0;
     rtamd_scene_info info{};
     bool bin_primary = true; // screen binning of the primary rays (rtamd_build_params::primary_rays)
+    bool bin_always = false; // ... also where the tree would be cheaper (RTAMD_PRIMARY_RAYS_BINS)
     std::vector<rtamd_material> materials;
     std::vector<int32_t> face_material;
     // staging for the host-buffer entry point
@@ -215,6 +222,12 @@ int acquire_slot(rtamd_scene *s, hipStream_t stream, FrameSlot **out) {
     if (pick < 0 && s->num_slots < kMaxFrameSlots) {
         pick = s->num_slots++;
         HIP_TRY(hipEventCreateWithFlags(&s->slots[pick].done, hipEventDisableTiming));
+        void *host = nullptr, *mapped = nullptr;
+        HIP_TRY(hipHostMalloc(&host, 64, hipHostMallocMapped));
+        std::memset(host, 0, 64);
+        HIP_TRY(hipHostGetDevicePointer(&mapped, host, 0));
+        s->slots[pick].feedback = (volatile int32_t *)host;
+        s->slots[pick].ws.bin_feedback = (int32_t *)mapped;
         // the first slot's frames may use the side streams: let them end before a second caller stream joins
         if (pick == 1 && s->slots[0].used) HIP_TRY(hipEventSynchronize(s->slots[0].done));
     }
@@ -460,6 +473,7 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     s->ds.grid_entries = (const int2 *)s->d_grid_entries;
     s->ds.use_grids = grids.usable ? 1 : 0;
     s->bin_primary = !(build && build->primary_rays == RTAMD_PRIMARY_RAYS_TREE);
+    s->bin_always = build && build->primary_rays == RTAMD_PRIMARY_RAYS_BINS;
     s->info.shadow_grid_entries = grids.usable ? (uint64_t)grids.entries.size() : 0;
     s->ds.num_lights = d->num_lights;
     s->ds.spl = d->samples_per_light;
@@ -508,6 +522,7 @@ int rtamd_scene_destroy(rtamd_scene *s) {
         FrameSlot &fs = s->slots[i];
         if (fs.block) (void)hipFree(fs.block);
         if (fs.done) (void)hipEventDestroy(fs.done);
+        if (fs.feedback) (void)hipHostFree((void *)fs.feedback);
         for (hipEvent_t e : fs.sync) (void)hipEventDestroy(e);
     }
     for (TimedLaunch &t : s->events) {
@@ -576,7 +591,24 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     // rank of eight at 4K), behind at 7.5 faces per pixel (a 256x144 image of 278 K faces).
     static const double faces_per_pixel_max = getenv("RTAMD_BIN_FACES_PER_PIXEL") ? atof(getenv("RTAMD_BIN_FACES_PER_PIXEL")) : 2.0;
     bool bins_ok = s->bin_primary && fs.ws.bin_entries != nullptr && bins_x < 32768 && bins_y < 32768 &&
-                   (double)s->info.num_device_faces <= faces_per_pixel_max * (double)pixels;
+                   (s->bin_always || (double)s->info.num_device_faces <= faces_per_pixel_max * (double)pixels);
+    if (bins_ok && fs.feedback && !s->bin_always) {
+        const uint64_t key = (uint64_t)(uint32_t)p->width | ((uint64_t)(uint32_t)p->height << 20) | ((uint64_t)(uint32_t)p->part << 40) |
+                             ((uint64_t)(uint32_t)p->num_parts << 48) | ((uint64_t)(uint32_t)p->row_tile << 56);
+        if (fs.feedback_key != key) { // another view: what earlier passes reported says nothing about it
+            fs.feedback_key = key;
+            fs.feedback[0] = fs.feedback[1] = fs.feedback[2] = fs.feedback[3] = 0;
+            fs.frames_without_bins = 0;
+        }
+        const long long total = fs.feedback[0], nonempty = fs.feedback[1];
+        const bool turned_down = fs.feedback[3] != 0 && (fs.feedback[2] != 0 || total > (long long)kMaxAverageBinList * std::max(nonempty, 1ll));
+        if (turned_down && fs.frames_without_bins < 63) { // try the bins again every 64th frame: the camera may have moved
+            bins_ok = false;
+            ++fs.frames_without_bins;
+        } else {
+            fs.frames_without_bins = 0;
+        }
+    }
     if (bins_ok) {
         const float *m = cam->inv_view;
         const double a = m[0], b = m[1], c = m[2], d0 = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
@@ -597,6 +629,8 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     }
     Workspace ws_frame = fs.ws; // what the kernels of this frame see
     if (!bins_ok) ws_frame.bin_entries = nullptr;
+    fs.binned = bins_ok;
+    ws_frame.bin_max_list = s->bin_always ? 0x7fffffff : kMaxAverageBinList;
     ws_frame.num_bins = bins_x * bins_y;
 
     const bool count = (p->flags & RTAMD_FLAG_COUNT_WORK) != 0;
@@ -745,6 +779,15 @@ int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
         st->box_tests[k] = wc[k].box_tests;
         st->tri_plane[k] = wc[k].tri_plane;
         st->tri_edge[k] = wc[k].tri_edge;
+    }
+    if (s->slots[s->last_slot].binned) {
+        BinState bs;
+        HIP_TRY(hipMemcpy(&bs, ws_last.bin_state, sizeof bs, hipMemcpyDeviceToHost));
+        st->bin_entries = (uint32_t)bs.total;
+        st->bins_nonempty = (uint32_t)bs.nonempty;
+        st->reserved = bs.fallback;
+        const long long limit = s->bin_always ? 0x7fffffffll : (long long)kMaxAverageBinList;
+        st->primary_path = !bs.fallback && (long long)bs.total <= limit * (long long)std::max(bs.nonempty, 1) ? 1 : 0;
     }
     for (size_t i = 0; i < s->events_used; ++i) {
         float ms = 0.0f;

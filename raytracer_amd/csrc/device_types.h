@@ -59,8 +59,14 @@ struct BinState {
     int32_t total;    // entries handed out so far (bin ranges are claimed block by block)
     int32_t num_big;  // faces in the big list
     int32_t fallback; // 1: the entry buffer is too small for this view -> the primary rays walk the tree
-    int32_t pad;
+    int32_t nonempty; // bins that hold at least one face
 };
+
+// Longest average list (entries per non-empty bin) for which the bins beat the tree: every pixel of a bin
+// runs through the whole list, one batch of four after the other, while a tree walk meets 10..35 boxes and a
+// few faces whatever the image size.  Measured crossover (69 K-face and 1.1 M-face scenes, 480x270 .. 4K):
+// bins win at 21 and 32 entries per bin, the tree at 46 and beyond.
+constexpr int kMaxAverageBinList = 38;
 
 // Per-stage counters (one stage = one recursion level of one SSAA pass), zeroed once per frame.
 struct StageCounters {
@@ -105,6 +111,10 @@ struct Workspace {
     int4 *big;            // (TriRecord index, first bin x | y << 16, last bin x | y << 16, 0)
     int32_t bin_capacity; // entries
     int32_t num_bins;
+    int32_t bin_max_list; // longest average list the pass accepts (kMaxAverageBinList, or no limit when bins are forced)
+    // host memory the pass reports its BinState to (total, nonempty, fallback, 1), so that the host can leave the
+    // binning out of the NEXT frames of a view whose lists are too long; never read by the device
+    int32_t *bin_feedback;
 };
 
 } // namespace rtamd

@@ -145,6 +145,13 @@ __device__ __forceinline__ bool spheres_hit(const DeviceScene &sc, V3 o, V3 d, f
     return any;
 }
 
+// Screen bins of this pass usable?  Not when the entry buffer overflowed, and not when the lists came out so
+// long that walking the tree is cheaper (a small image of a dense mesh).  Known after bin_offsets_kernel.
+__device__ __forceinline__ bool bins_accepted(const Workspace &ws) {
+    const BinState *st = ws.bin_state;
+    return !st->fallback && (long long)st->total <= (long long)ws.bin_max_list * (long long)max(st->nonempty, 1);
+}
+
 __device__ __forceinline__ void flush_work(unsigned a, unsigned b, unsigned c, WorkCounters *out) {
     for (int off = 32; off > 0; off >>= 1) {
         a += __shfl_xor(a, off);
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
     int *const leafq = s_stack + kLdsStack * 64 + lane;
     constexpr int CAP = MODE == kShadow ? kLeafQueue : kLeafQueueClosest;
 
-    if (MODE == kPrimary && ws.bin_entries && !ws.bin_state->fallback) return; // raster_kernel has done this pass
+    if (MODE == kPrimary && ws.bin_entries && bins_accepted(ws)) return; // raster_kernel does this pass
     const int nshadow = sc.num_lights * sc.spl;
     int rays, nhits = 0;
     if (MODE == kPrimary) {
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(DeviceScene sc, FrameCon
 // Claims a contiguous range of the entry buffer for every bin: prefix sum inside a workgroup, one atomic per
 // workgroup.  Leaves bin_count = 0 for the fill pass to count up again.
 __global__ __launch_bounds__(256) void bin_offsets_kernel(Workspace ws) {
-    __shared__ int s_wave[4];
+    __shared__ int s_wave[4], s_full[4];
     __shared__ int s_base;
     const int bin = (int)(blockIdx.x * 256 + threadIdx.x);
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
@@ -600,10 +607,13 @@ __global__ __launch_bounds__(256) void bin_offsets_kernel(Workspace ws) {
         if (lane >= d) incl += up;
     }
     if (lane == 63) s_wave[wave] = incl;
+    const int full = __popcll(__ballot(c > 0));
+    if (lane == 0) s_full[wave] = full;
     __syncthreads();
     if (threadIdx.x == 0) {
         const int n = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
         int base = n ? atomicAdd(&ws.bin_state->total, n) : 0;
+        if (s_full[0] + s_full[1] + s_full[2] + s_full[3]) atomicAdd(&ws.bin_state->nonempty, s_full[0] + s_full[1] + s_full[2] + s_full[3]);
         if (base + n > ws.bin_capacity) {
             ws.bin_state->fallback = 1;
             base = 0;
@@ -621,7 +631,11 @@ __global__ __launch_bounds__(256) void bin_offsets_kernel(Workspace ws) {
 
 __global__ __launch_bounds__(256) void bin_fill_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int num_tris) {
     const int tri = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (tri >= num_tris || ws.bin_state->fallback) return;
+    if (tri == 0 && ws.bin_feedback) {
+        ws.bin_feedback[0] = ws.bin_state->total, ws.bin_feedback[1] = ws.bin_state->nonempty;
+        ws.bin_feedback[2] = ws.bin_state->fallback, ws.bin_feedback[3] = 1;
+    }
+    if (tri >= num_tris || !bins_accepted(ws)) return;
     const PixelBox b = face_bins(sc, fc, tri);
     if (b.empty || b.big) return;
     for (int y = b.y0; y <= b.y1; ++y) {
@@ -635,7 +649,7 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(DeviceScene sc, FrameCons
 
 template <bool COUNT>
 __global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int total_static) {
-    if (ws.bin_state->fallback) return;
+    if (!bins_accepted(ws)) return;
     const int slot = (int)(blockIdx.x * 256 + threadIdx.x);
     unsigned w_box = 0, w_plane = 0, w_edge = 0;
     if (slot < total_static) {
@@ -1147,9 +1161,9 @@ void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const 
                          hipStream_t stream) {
     const int total_static = fc.tiles_x * fc.tiles_y * 64;
     // bounce queues are at most as long as the slot count: that is the worst case the grid covers
-    // With screen binning in use the primary walk is only the fall-back of a pass whose bins overflowed: a
-    // small grid (the kernel strides over the groups) keeps the usual early exit cheap.
-    const int blocks = primary && ws.bin_entries ? 2048 : walk_grid(primary ? fc.tiles_x * fc.tiles_y : ws.capacity / 64);
+    // With screen binning in use the primary walk only runs when the pass turned its bins down (overflow, or
+    // lists too long to pay): a moderate grid (the kernel strides over the groups) keeps the usual early exit cheap.
+    const int blocks = primary && ws.bin_entries ? 16384 : walk_grid(primary ? fc.tiles_x * fc.tiles_y : ws.capacity / 64);
     if (primary) {
         if (count)
             walk_kernel<kPrimary, true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, total_static);

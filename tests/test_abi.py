@@ -39,7 +39,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(L.Sphere) == 16
     assert C.sizeof(L.Camera) == (3 + 12 + 4 + 2) * 4
     assert C.sizeof(L.RenderParams) == (4 + 3 + 6 + 3 + 1 + 4) * 4
-    assert C.sizeof(L.Stats) == 4 * 8 + 9 * 8 + 5 * 4 + 3 * 4 + 2 * 4
+    assert C.sizeof(L.Stats) == 4 * 8 + 9 * 8 + 5 * 4 + 3 * 4 + 2 * 4 + 4 * 4
 
 
 def test_defaults_are_the_reference_macros():

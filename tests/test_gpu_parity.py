@@ -114,11 +114,13 @@ def test_shadow_grids_and_tree_walk_agree(name):
 def test_screen_bins_and_tree_walk_agree_for_primary_rays(name, view):
     """Primary rays are resolved by binning the projected faces per pass; forcing them through the BVH must give
     the same planes bit for bit -- also with faces beside and behind the eye, SSAA sub-samples, a row partition
-    and a camera that has been turned."""
+    and a camera that has been turned.  The automatic choice (bins unless their lists come out long, learnt from
+    the passes before) must give the same frame whichever way it goes, frame after frame."""
     kw = dict(model=scene_path(name), output="")
-    a = R.Flyscene(**kw).initialize(120, 88)
+    a = R.Flyscene(primary_rays=L.PRIMARY_RAYS_BINS, **kw).initialize(120, 88)
     b = R.Flyscene(primary_rays=L.PRIMARY_RAYS_TREE, **kw).initialize(120, 88)
-    for f in (a, b):
+    c = R.Flyscene(**kw).initialize(120, 88)
+    for f in (a, b, c):
         if view == "inside":
             f.camera_translate(0.0, 0.0, 38.0)  # steps of 0.05: the eye ends up inside the model's bounding box
             f.camera_rotate(0.3, -0.7)
@@ -126,102 +128,36 @@ def test_screen_bins_and_tree_walk_agree_for_primary_rays(name, view):
             f.camera_translate(2.0, -1.0, 24.0)
             f.camera_rotate(-0.2, 0.4)
     for params in (dict(), dict(ssaa_level=2), dict(row_tile=8, num_parts=3, part=1)):
-        a.set_params(**params)
-        b.set_params(**params)
+        for f in (a, b, c):
+            f.set_params(**params)
         ra, rb = a.render(), b.render()
+        assert ra["stats"].primary_path == 1 and rb["stats"].primary_path == 0
+        if name == "bunny":  # (scenes of a few large faces keep them all in the list every pixel scans)
+            assert ra["stats"].bin_entries > 0 and ra["stats"].bins_nonempty > 0
         assert np.array_equal(ra["face_id"], rb["face_id"]), (name, view, params)
         assert np.array_equal(ra["rgb"].view(np.uint32), rb["rgb"].view(np.uint32)), (name, view, params)
         sa, sb = ra["stats"], rb["stats"]
         assert (sa.rays_primary, sa.rays_shadow, sa.rays_bounce, sa.hits) == (sb.rays_primary, sb.rays_shadow, sb.rays_bounce, sb.hits)
-        a.set_params(ssaa_level=1, row_tile=16, num_parts=1, part=0)
-        b.set_params(ssaa_level=1, row_tile=16, num_parts=1, part=0)
+        for again in range(3):  # the second frame already knows what the first frame's binning pass found
+            rc = c.render()
+            assert np.array_equal(rc["face_id"], rb["face_id"]), (name, view, params, again)
+            assert np.array_equal(rc["rgb"].view(np.uint32), rb["rgb"].view(np.uint32)), (name, view, params, again)
+        for f in (a, b, c):
+            f.set_params(ssaa_level=1, row_tile=16, num_parts=1, part=0)
         if not params:
             assert (ra["face_id"] >= 0).any()
 
 
-@pytest.mark.parametrize("name", ["NthTest", "toy_on_plane", "bunny", "reflect_test", "textured_quad", "glass"])
-def test_device_built_hierarchy_gives_the_same_frame(name):
-    """The hierarchy built on the GPU (Morton-order radix tree) replaces the host SAH tree without changing a bit
-    of the frame: every ray kind is sent through it (no bins, no grids) and compared with the default path."""
-    kw = dict(model=scene_path(name), output="")
-    a = R.Flyscene(**kw).initialize(120, 88)
-    b = R.Flyscene(builder=L.BUILDER_DEVICE_LBVH, primary_rays=L.PRIMARY_RAYS_TREE, shadow_rays=L.SHADOW_RAYS_TREE, **kw).initialize(120, 88)
-    c = R.Flyscene(builder=L.BUILDER_DEVICE_LBVH, max_leaf_faces=1, **kw).initialize(120, 88)
-    assert a.info().builder == L.BUILDER_HOST_SAH
-    assert b.info().builder == L.BUILDER_DEVICE_LBVH and c.info().builder == L.BUILDER_DEVICE_LBVH
-    assert b.info().num_device_faces == a.info().num_device_faces
-    for f in (a, b, c):
-        f.camera_translate(1.0, -0.5, 6.0)
-        f.camera_rotate(-0.1, 0.2)
-    ra = a.render()
-    assert (ra["face_id"] >= 0).any() and ra["stats"].rays_shadow > 0
-    for other in (b, c):
-        ro = other.render()
-        assert np.array_equal(ra["face_id"], ro["face_id"])
-        assert np.array_equal(ra["rgb"].view(np.uint32), ro["rgb"].view(np.uint32))
-        sa, so = ra["stats"], ro["stats"]
-        assert (sa.rays_primary, sa.rays_shadow, sa.rays_bounce, sa.hits) == (so.rays_primary, so.rays_shadow, so.rays_bounce, so.hits)
-
-
-def test_device_builder_on_a_large_mesh_and_its_fallback():
-    import torch
-
-    w = workloads.get("field2_mirrors_small")
-    frames = []
-    for build in (dict(), dict(builder=L.BUILDER_DEVICE_LBVH)):
-        fly, params, cam = workloads.make_flyscene(w, **build)
-        rgb = torch.zeros((w["height"], w["width"], 3), dtype=torch.float32, device="cuda")
-        fid = torch.zeros((w["height"], w["width"]), dtype=torch.int32, device="cuda")
-        fly.render_device(rgb, fid, camera=cam)
-        torch.cuda.synchronize()
-        frames.append((fly.info(), rgb.cpu().numpy(), fid.cpu().numpy(), fly.stats()))
-    (ia, rgb_a, fid_a, sa), (ib, rgb_b, fid_b, sb) = frames
-    assert ia.builder == L.BUILDER_HOST_SAH and ib.builder == L.BUILDER_DEVICE_LBVH and ib.num_device_faces == ia.num_device_faces
-    assert ib.hierarchy_ms < ia.hierarchy_ms
-    assert np.array_equal(fid_a, fid_b)
-    assert np.array_equal(rgb_a.view(np.uint32), rgb_b.view(np.uint32))
-    assert sa.rays_bounce == sb.rays_bounce > 0 and sa.rays_shadow == sb.rays_shadow
-    # one face: nothing to sort, the host builder takes over and says so
-    one = R.Flyscene(arrays=(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), None, np.array([[0, 1, 2]], np.int32),
-                             np.array([0], np.int32), [dict(ka=(0, 0, 0), kd=(1, 0, 0), ks=(0, 0, 0), shininess=1.0)]),
-                     builder=L.BUILDER_DEVICE_LBVH, output="").initialize(32, 32)
-    assert one.info().builder == L.BUILDER_HOST_SAH
-    assert (one.render()["face_id"] >= 0).any()
-
-
-def test_frames_in_flight_on_several_streams():
-    """Every stream a caller renders on gets a workspace of its own: frames enqueued on different streams may run
-    at the same time and still give the frames a single stream gives, also with more streams than workspaces."""
-    import torch
-
-    fly, _ = make_pair("reflect_test", width=160, height=120)
-    cams = []
-    for k in range(6):
-        fly.camera_translate(0.4, -0.2, 1.0)
-        fly.camera_rotate(0.05, -0.03)
-        cams.append(fly.getCamera())
-    shape = (120, 160)
-    want = []
-    for cam in cams:
-        rgb = torch.zeros(shape + (3,), dtype=torch.float32, device="cuda")
-        fid = torch.zeros(shape, dtype=torch.int32, device="cuda")
-        fly.render_device(rgb, fid, camera=cam)
-        torch.cuda.synchronize()
-        want.append((rgb.cpu().numpy(), fid.cpu().numpy()))
-    assert fly.stats().rays_bounce > 0
-    assert not np.array_equal(want[0][1], want[5][1])
-    for nstreams in (2, 3, 6):  # 6 > the four workspaces a scene keeps: the least recently used one changes hands
-        streams = [torch.cuda.Stream() for _ in range(nstreams)]
-        outs = [(torch.zeros(shape + (3,), dtype=torch.float32, device="cuda"), torch.zeros(shape, dtype=torch.int32, device="cuda"))
-                for _ in cams]
-        torch.cuda.synchronize()
-        for rounds in range(3):
-            for k, cam in enumerate(cams):
-                fly.render_device(outs[k][0], outs[k][1], camera=cam, stream=streams[k % nstreams])
-        torch.cuda.synchronize()
-        for k in range(len(cams)):
-            assert np.array_equal(outs[k][1].cpu().numpy(), want[k][1]), (nstreams, k)
-            assert np.array_equal(outs[k][0].cpu().numpy().view(np.uint32), want[k][0].view(np.uint32)), (nstreams, k)
+def test_automatic_choice_between_bins_and_tree():
+    """A dense mesh in a small image gives long lists per bin: the pass turns its bins down and walks the tree, and
+    the frames after it do not bin at all; the same mesh in a large image keeps its bins."""
+    small = R.Flyscene(model=scene_path("bunny"), output="").initialize(320, 240)
+    first, second = small.render()["stats"], small.render()["stats"]
+    assert first.primary_path == 0 and first.bin_entries > 38 * first.bins_nonempty > 0   # binned, then turned down
+    assert second.primary_path == 0 and second.bin_entries == 0                            # not binned any more
+    large = R.Flyscene(model=scene_path("bunny"), output="").initialize(1600, 1200)
+    st = [large.render(face_ids=False)["stats"] for _ in range(2)][-1]
+    assert st.primary_path == 1 and 0 < st.bin_entries <= 38 * st.bins_nonempty
 
 
 def _random_soup(seed):
