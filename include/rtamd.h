@@ -172,7 +172,7 @@ typedef struct {
     uint32_t bins_nonempty;  /* bins holding at least one face                                    */
     int32_t primary_path;    /* 1: primary rays were resolved through the bins, 0: by the BVH walk
                               * (no binning, bin buffer too small, or lists too long to pay)      */
-    int32_t reserved;
+    int32_t bin_overflow;    /* 1: the bin buffer was too small for the view                      */
 } rtamd_stats;
 
 typedef struct {

@@ -70,7 +70,7 @@ class Stats(C.Structure):
         ("ms_trace", C.c_float), ("ms_shadow", C.c_float), ("ms_compact", C.c_float), ("ms_shade", C.c_float),
         ("ms_frames", C.c_float), ("launches_trace", C.c_int32), ("launches_shadow", C.c_int32), ("frames", C.c_int32),
         ("ms_raster", C.c_float), ("launches_raster", C.c_int32),
-        ("bin_entries", C.c_uint32), ("bins_nonempty", C.c_uint32), ("primary_path", C.c_int32), ("reserved", C.c_int32),
+        ("bin_entries", C.c_uint32), ("bins_nonempty", C.c_uint32), ("primary_path", C.c_int32), ("bin_overflow", C.c_int32),
     ]
 
     @property

@@ -785,7 +785,7 @@ int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
         HIP_TRY(hipMemcpy(&bs, ws_last.bin_state, sizeof bs, hipMemcpyDeviceToHost));
         st->bin_entries = (uint32_t)bs.total;
         st->bins_nonempty = (uint32_t)bs.nonempty;
-        st->reserved = bs.fallback;
+        st->bin_overflow = bs.fallback;
         const long long limit = s->bin_always ? 0x7fffffffll : (long long)kMaxAverageBinList;
         st->primary_path = !bs.fallback && (long long)bs.total <= limit * (long long)std::max(bs.nonempty, 1) ? 1 : 0;
     }

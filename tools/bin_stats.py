@@ -14,4 +14,4 @@ for k in range(4):
     torch.cuda.synchronize()
     st = fly.stats()
     print("frame %d: bin entries %d, non-empty bins %d, list %.1f, primary path %d, overflow %d" %
-          (k, st.bin_entries, st.bins_nonempty, st.bin_entries / max(st.bins_nonempty, 1), st.primary_path, st.reserved), flush=True)
+          (k, st.bin_entries, st.bins_nonempty, st.bin_entries / max(st.bins_nonempty, 1), st.primary_path, st.bin_overflow), flush=True)
