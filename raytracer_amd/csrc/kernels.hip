@@ -511,7 +511,8 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
 // three-edge test over the list of its bin and keeps the nearest face under the reference's tie rule.  The
 // exact test decides, so the result is the one the tree walk gives.  Faces with a vertex at or behind the
 // eye plane, or covering more than kBigBins bins, go to a short list that every pixel scans with a box
-// check.  When the entry buffer would overflow the pass sets BinState::fallback and the tree walk runs.
+// check.  When the entry buffer would overflow (BinState::fallback), or the lists come out longer on average than
+// a tree walk is worth (bins_accepted), the pass leaves its bins alone and the tree walk runs.
 // ---------------------------------------------------------------------------------------------
 struct PixelBox {
     int x0, y0, x1, y1; // bins, inclusive, clamped to the image
