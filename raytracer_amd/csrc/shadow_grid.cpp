@@ -1,6 +1,7 @@
 #include "shadow_grid.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -21,7 +22,23 @@ struct OneGrid {
     bool ok = false;
 };
 
-void build_one(const FlatBvh &bvh, const float *dir, double scale, OneGrid &g) {
+// Runs fn(first, last) over [0, n) on `threads` threads (the calling one included).
+template <class F>
+void parallel_ranges(size_t n, int threads, F fn) {
+    if (threads <= 1 || n < 4096) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(fn, n * (size_t)t / (size_t)threads, n * (size_t)(t + 1) / (size_t)threads);
+    fn((size_t)0, n / (size_t)threads);
+    for (std::thread &t : pool) t.join();
+}
+
+// One grid, built by `threads` threads: projection, counting and filling run over ranges of faces (atomic
+// per-cell counters), the sort of the lists over ranges of cells; the sort makes the result independent of the
+// order in which the threads filled the lists.
+void build_one(const FlatBvh &bvh, const float *dir, double scale, OneGrid &g, int threads) {
     const double dx = dir[0], dy = dir[1], dz = dir[2];
     const double len2 = dx * dx + dy * dy + dz * dz;
     if (!std::isfinite(len2) || !(len2 > 1e-60)) return;
@@ -47,24 +64,43 @@ void build_one(const FlatBvh &bvh, const float *dir, double scale, OneGrid &g) {
         float ulo, uhi, vlo, vhi, zmax;
     };
     std::vector<Box2> box(n);
-    double gu0 = DBL_MAX, gu1 = -DBL_MAX, gv0 = DBL_MAX, gv1 = -DBL_MAX;
-    for (size_t i = 0; i < n; ++i) {
-        const TriRecord &t = bvh.tris[i];
-        const float *vs[3] = {t.v0, t.v1, t.v2};
-        double ulo = DBL_MAX, uhi = -DBL_MAX, vlo = DBL_MAX, vhi = -DBL_MAX, zhi = -DBL_MAX;
-        for (const float *p : vs) {
-            const double u = (double)p[0] * Uf[0] + (double)p[1] * Uf[1] + (double)p[2] * Uf[2];
-            const double v = (double)p[0] * Vf[0] + (double)p[1] * Vf[1] + (double)p[2] * Vf[2];
-            const double z = (double)p[0] * Wf[0] + (double)p[1] * Wf[1] + (double)p[2] * Wf[2];
-            ulo = std::min(ulo, u), uhi = std::max(uhi, u), vlo = std::min(vlo, v), vhi = std::max(vhi, v), zhi = std::max(zhi, z);
+    struct Extent {
+        double u0 = DBL_MAX, u1 = -DBL_MAX, v0 = DBL_MAX, v1 = -DBL_MAX;
+        bool finite = true;
+    };
+    std::vector<Extent> part((size_t)std::max(threads, 1));
+    std::atomic<int> next_part{0};
+    parallel_ranges(n, threads, [&](size_t first, size_t last) {
+        Extent e;
+        for (size_t i = first; i < last; ++i) {
+            const TriRecord &t = bvh.tris[i];
+            const float *vs[3] = {t.v0, t.v1, t.v2};
+            double ulo = DBL_MAX, uhi = -DBL_MAX, vlo = DBL_MAX, vhi = -DBL_MAX, zhi = -DBL_MAX;
+            for (const float *p : vs) {
+                const double u = (double)p[0] * Uf[0] + (double)p[1] * Uf[1] + (double)p[2] * Uf[2];
+                const double v = (double)p[0] * Vf[0] + (double)p[1] * Vf[1] + (double)p[2] * Vf[2];
+                const double z = (double)p[0] * Wf[0] + (double)p[1] * Wf[1] + (double)p[2] * Wf[2];
+                ulo = std::min(ulo, u), uhi = std::max(uhi, u), vlo = std::min(vlo, v), vhi = std::max(vhi, v), zhi = std::max(zhi, z);
+            }
+            if (!std::isfinite(ulo + uhi + vlo + vhi + zhi)) {
+                e.finite = false;
+                break;
+            }
+            Box2 &b = box[i];
+            b = Box2{(float)(ulo - margin), (float)(uhi + margin), (float)(vlo - margin), (float)(vhi + margin), (float)(zhi + margin)};
+            b.ulo = std::nextafterf(b.ulo, -FLT_MAX), b.uhi = std::nextafterf(b.uhi, FLT_MAX);
+            b.vlo = std::nextafterf(b.vlo, -FLT_MAX), b.vhi = std::nextafterf(b.vhi, FLT_MAX);
+            b.zmax = std::nextafterf(b.zmax, FLT_MAX);
+            e.u0 = std::min(e.u0, (double)b.ulo), e.u1 = std::max(e.u1, (double)b.uhi);
+            e.v0 = std::min(e.v0, (double)b.vlo), e.v1 = std::max(e.v1, (double)b.vhi);
         }
-        if (!std::isfinite(ulo + uhi + vlo + vhi + zhi)) return;
-        box[i] = Box2{(float)(ulo - margin), (float)(uhi + margin), (float)(vlo - margin), (float)(vhi + margin), (float)(zhi + margin)};
-        box[i].ulo = std::nextafterf(box[i].ulo, -FLT_MAX), box[i].uhi = std::nextafterf(box[i].uhi, FLT_MAX);
-        box[i].vlo = std::nextafterf(box[i].vlo, -FLT_MAX), box[i].vhi = std::nextafterf(box[i].vhi, FLT_MAX);
-        box[i].zmax = std::nextafterf(box[i].zmax, FLT_MAX);
-        gu0 = std::min(gu0, (double)box[i].ulo), gu1 = std::max(gu1, (double)box[i].uhi);
-        gv0 = std::min(gv0, (double)box[i].vlo), gv1 = std::max(gv1, (double)box[i].vhi);
+        part[(size_t)next_part.fetch_add(1)] = e;
+    });
+    double gu0 = DBL_MAX, gu1 = -DBL_MAX, gv0 = DBL_MAX, gv1 = -DBL_MAX;
+    for (int k = 0; k < next_part.load(); ++k) {
+        const Extent &e = part[(size_t)k];
+        if (!e.finite) return;
+        gu0 = std::min(gu0, e.u0), gu1 = std::max(gu1, e.u1), gv0 = std::min(gv0, e.v0), gv1 = std::max(gv1, e.v1);
     }
     if (n == 0) gu0 = gv0 = 0.0, gu1 = gv1 = 1.0;
     const double extent = std::max(std::max(gu1 - gu0, gv1 - gv0), 1e-30);
@@ -79,36 +115,48 @@ void build_one(const FlatBvh &bvh, const float *dir, double scale, OneGrid &g) {
             const float f = std::floor((x - origin) * inv_cell);
             return (int)std::min(std::max(f, 0.0f), (float)(res - 1));
         };
-        std::vector<int32_t> count((size_t)res * res + 1, 0);
-        int64_t total = 0;
-        for (size_t i = 0; i < n; ++i) {
-            const int x0 = cell(box[i].ulo, u0), x1 = cell(box[i].uhi, u0), y0 = cell(box[i].vlo, v0), y1 = cell(box[i].vhi, v0);
-            total += (int64_t)(x1 - x0 + 1) * (y1 - y0 + 1);
-            if (total > kMaxEntriesPerGrid) break;
-            for (int y = y0; y <= y1; ++y)
-                for (int x = x0; x <= x1; ++x) ++count[(size_t)y * res + x];
-        }
-        if (total > kMaxEntriesPerGrid) {
+        const size_t ncells = (size_t)res * res;
+        std::vector<std::atomic<int32_t>> count(ncells);
+        for (std::atomic<int32_t> &c : count) c.store(0, std::memory_order_relaxed);
+        std::atomic<int64_t> total{0};
+        parallel_ranges(n, threads, [&](size_t first, size_t last) {
+            int64_t mine = 0;
+            for (size_t i = first; i < last && total.load(std::memory_order_relaxed) <= kMaxEntriesPerGrid; ++i) {
+                const int x0 = cell(box[i].ulo, u0), x1 = cell(box[i].uhi, u0), y0 = cell(box[i].vlo, v0), y1 = cell(box[i].vhi, v0);
+                const int64_t add = (int64_t)(x1 - x0 + 1) * (y1 - y0 + 1);
+                mine += add;
+                if (mine > kMaxEntriesPerGrid) break;
+                for (int y = y0; y <= y1; ++y)
+                    for (int x = x0; x <= x1; ++x) count[(size_t)y * res + x].fetch_add(1, std::memory_order_relaxed);
+            }
+            total.fetch_add(mine);
+        });
+        if (total.load() > kMaxEntriesPerGrid) {
             if (res <= 16) return;
             continue;
         }
-        g.start.assign((size_t)res * res + 1, 0);
+        g.start.assign(ncells + 1, 0);
         int32_t run = 0;
-        for (size_t c = 0; c < (size_t)res * res; ++c) {
+        for (size_t c = 0; c < ncells; ++c) {
             g.start[c] = run;
-            run += count[c];
+            run += count[c].load(std::memory_order_relaxed);
+            count[c].store(g.start[c], std::memory_order_relaxed); // from here on: the fill cursor of the cell
         }
-        g.start[(size_t)res * res] = run;
+        g.start[ncells] = run;
         g.entries.resize((size_t)run);
-        std::vector<int32_t> fill(g.start.begin(), g.start.end() - 1);
-        for (size_t i = 0; i < n; ++i) {
-            const int x0 = cell(box[i].ulo, u0), x1 = cell(box[i].uhi, u0), y0 = cell(box[i].vlo, v0), y1 = cell(box[i].vhi, v0);
-            for (int y = y0; y <= y1; ++y)
-                for (int x = x0; x <= x1; ++x) g.entries[(size_t)fill[(size_t)y * res + x]++] = ShadowGridEntry{(int32_t)i, box[i].zmax};
-        }
-        for (size_t c = 0; c < (size_t)res * res; ++c)
-            std::sort(g.entries.begin() + g.start[c], g.entries.begin() + g.start[c + 1],
-                      [](const ShadowGridEntry &p, const ShadowGridEntry &q) { return p.zmax > q.zmax || (p.zmax == q.zmax && p.tri < q.tri); });
+        parallel_ranges(n, threads, [&](size_t first, size_t last) {
+            for (size_t i = first; i < last; ++i) {
+                const int x0 = cell(box[i].ulo, u0), x1 = cell(box[i].uhi, u0), y0 = cell(box[i].vlo, v0), y1 = cell(box[i].vhi, v0);
+                for (int y = y0; y <= y1; ++y)
+                    for (int x = x0; x <= x1; ++x)
+                        g.entries[(size_t)count[(size_t)y * res + x].fetch_add(1, std::memory_order_relaxed)] = ShadowGridEntry{(int32_t)i, box[i].zmax};
+            }
+        });
+        parallel_ranges(ncells, threads, [&](size_t first, size_t last) {
+            for (size_t c = first; c < last; ++c)
+                std::sort(g.entries.begin() + g.start[c], g.entries.begin() + g.start[c + 1],
+                          [](const ShadowGridEntry &p, const ShadowGridEntry &q) { return p.zmax > q.zmax || (p.zmax == q.zmax && p.tri < q.tri); });
+        });
         std::memcpy(g.h.U, Uf, 12), std::memcpy(g.h.V, Vf, 12), std::memcpy(g.h.W, Wf, 12);
         g.h.u0 = u0, g.h.v0 = v0, g.h.inv_cell = inv_cell, g.h.res = res;
         g.ok = true;
@@ -127,11 +175,14 @@ void build_shadow_grids(const FlatBvh &bvh, const float *samples, int num_sample
     if (!std::isfinite(scale)) return;
 
     std::vector<OneGrid> grids((size_t)num_samples);
-    const int workers = std::max(1, std::min(num_samples, std::min(16, (int)std::thread::hardware_concurrency())));
+    // up to 16 threads in all: one per sample, and the rest inside the samples when those are few
+    const int budget = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+    const int workers = std::min(num_samples, budget);
+    const int inner = std::max(1, budget / workers);
     std::vector<std::thread> pool;
     for (int w = 0; w < workers; ++w)
         pool.emplace_back([&, w] {
-            for (int k = w; k < num_samples; k += workers) build_one(bvh, samples + 3 * (size_t)k, scale, grids[(size_t)k]);
+            for (int k = w; k < num_samples; k += workers) build_one(bvh, samples + 3 * (size_t)k, scale, grids[(size_t)k], inner);
         });
     for (std::thread &t : pool) t.join();
 
