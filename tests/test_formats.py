@@ -1,6 +1,7 @@
 """File formats either side of the path: PLY ingestion (binary little-endian and ascii) and binary PPM output.
 The reference reads OBJ only on this path and previews PLY (utils/plyimporter.hpp:213-284); a PLY holding the
 same vertices, normals and faces as an OBJ must flatten to bit-identical arrays.  No GPU."""
+import os
 import struct
 
 import numpy as np
@@ -92,3 +93,14 @@ def test_binary_ppm_holds_the_same_bytes_as_the_text_form(tmp_path):
     assert raw.startswith(b"P6\n7 5\n255\n") and len(raw) == 11 + 5 * 7 * 3
     # ppmIO.hpp:203 writes min(255, (int)(255*c)) unclamped below; the binary form clamps negatives to 0
     assert list(raw[11:]) == [max(int(x), 0) for x in text[4:]]
+
+
+@pytest.mark.parametrize("name", ["reflect_test_64", "NthTest_256", "bunny_256", "textured_quad_64"])
+def test_product_ppm_writer_gives_the_golden_file_bytes(name, tmp_path):
+    """The host writer of the product (ASCII P3, utils/ppmIO.hpp:188-209) turns the golden float frame into the
+    same bytes as the oracle's writer did when the fixture was made."""
+    import hashlib
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    R.write_ppm(str(tmp_path / "result.ppm"), g["rgb"])
+    assert hashlib.sha256((tmp_path / "result.ppm").read_bytes()).hexdigest() == str(g["ppm_sha256"])

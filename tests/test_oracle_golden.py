@@ -21,7 +21,7 @@ def digest(a):
 
 
 @pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p)[:-4] for p in FILES])
-def test_oracle_reproduces_golden(path):
+def test_oracle_reproduces_golden(path, tmp_path):
     g = np.load(path)
     name, size = os.path.basename(path)[:-4].rsplit("_", 1)
     s = OracleScene(scene_path(name))
@@ -36,6 +36,8 @@ def test_oracle_reproduces_golden(path):
     a = s.arrays()
     for k in ("vertices", "normals", "face_normals", "face_origin_distance", "face_vertex_ids", "face_material_ids", "light_samples"):
         assert digest(a[k]) == str(g["sha256_" + k]), k
+    write_ppm(str(tmp_path / "result.ppm"), r["rgb"])  # the file the reference leaves behind
+    assert hashlib.sha256((tmp_path / "result.ppm").read_bytes()).hexdigest() == str(g["ppm_sha256"])
     if "t" in g.files:
         assert np.array_equal(r["t"].view(np.uint32), g["t"].view(np.uint32))
         assert np.array_equal(r["light"].view(np.uint32), g["light"].view(np.uint32))

@@ -15,7 +15,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle.oracle_py import OracleScene  # noqa: E402
+import tempfile  # noqa: E402
+
+from oracle.oracle_py import OracleScene, write_ppm  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 SMALL = ["reflect_test", "reflect_test_2", "shadowmodel", "NthTest", "glass"]
@@ -48,6 +50,9 @@ def one(name, size, full):
     t = s.texture_arrays()
     out["sha256_face_texcoords"] = np.array(digest(t["face_texcoords"]))
     out["sha256_textures"] = np.array(digest(np.concatenate([im.reshape(-1) for im in t["images"]]) if t["images"] else np.zeros(0, np.float32)))
+    with tempfile.TemporaryDirectory() as tmp:  # the bytes of result.ppm (writePPMImage, utils/ppmIO.hpp:188-209)
+        write_ppm(os.path.join(tmp, "result.ppm"), r["rgb"])
+        out["ppm_sha256"] = np.array(hashlib.sha256(open(os.path.join(tmp, "result.ppm"), "rb").read()).hexdigest())
     if full:
         boxes, info = s.bvh_dump()
         out.update({"t": r["t"], "light": r["light"], "bvh_boxes": boxes, "bvh_info": info, "face_order": s.bvh_face_order(),
