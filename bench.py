@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--single-stream", action="store_true",
                     help="keep every frame on its caller's stream (no side streams): with --in-flight 1 every kernel then runs alone, "
                          "which is the mode the per-kernel profile under profiles/ is taken in")
+    ap.add_argument("--force-pipeline", action="store_true",
+                    help="run the several-GPU code path (gather pipeline, both payloads, single-GPU comparison) on one GPU: a rehearsal "
+                         "of everything but the collective itself")
     ap.add_argument("--gather", choices=("u8", "f32"), default="u8",
                     help="what the ranks send to rank 0: the 8-bit pixels the reference writes to result.ppm, or the float framebuffer")
     ap.add_argument("--builder", type=int, default=0, help="0 = host SAH builder, 1 = on-GPU Morton-order builder")
@@ -174,10 +177,11 @@ def main():
     rows = fly.local_rows(mine)
     # Frames in flight: frame k is enqueued on stream k % F into buffer k % F (the scene keeps one workspace per
     # stream), so the small, latency-bound launches of one frame overlap the other frames' work.
-    in_flight = max(1, min(a.in_flight, 4 if world == 1 else 2))
+    in_flight = max(1, min(a.in_flight, 4 if world == 1 and not a.force_pipeline else 2))
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(in_flight - 1)]
     turn = [0]
-    if world == 1:
+    piped = world > 1 or a.force_pipeline
+    if not piped:
         rgbs = [torch.zeros((max(rows, 1), W, 3), dtype=torch.float32, device=dev) for _ in range(in_flight)]
 
         def frame(p):
@@ -193,26 +197,27 @@ def main():
         # What is exchanged is what the reference keeps of a frame: the 8-bit pixels of result.ppm, quantised on
         # every rank with the file writer's expression (a quarter of the float framebuffer's bytes); --gather f32
         # sends the floats instead.
-        as_bytes = a.gather == "u8"
-        pipe = tiles.GatherPipeline(mine, W, 3, dev, dtype=torch.uint8 if as_bytes else torch.float32)
-        rgbs = [torch.zeros((max(rows, 1), W, 3), dtype=torch.float32, device=dev) for _ in range(in_flight)] if as_bytes else None
+        def make_pipeline(as_bytes):
+            pipe = tiles.GatherPipeline(mine, W, 3, dev, dtype=torch.uint8 if as_bytes else torch.float32)
+            bufs = [torch.zeros((max(rows, 1), W, 3), dtype=torch.float32, device=dev) for _ in range(in_flight)] if as_bytes else None
 
-        def frame(p):
-            k = turn[0] % in_flight
-            turn[0] += 1
-            buf = pipe.acquire(streams[k])
-            if as_bytes:
-                fly.render_device(rgbs[k], params=p, camera=cam, stream=streams[k])
-                tiles.quantize_ppm(rgbs[k], buf, rows * W * 3, stream=streams[k])
-            else:
-                fly.render_device(buf, params=p, camera=cam, stream=streams[k])
-            pipe.submit(streams[k])
+            def frame(p):
+                k = turn[0] % in_flight
+                turn[0] += 1
+                buf = pipe.acquire(streams[k])
+                if as_bytes:
+                    fly.render_device(bufs[k], params=p, camera=cam, stream=streams[k])
+                    tiles.quantize_ppm(bufs[k], buf, rows * W * 3, stream=streams[k])
+                else:
+                    fly.render_device(buf, params=p, camera=cam, stream=streams[k])
+                pipe.submit(streams[k])
 
-        def flush():
-            pipe.drain()
+            return frame, pipe.drain
 
-    def sync():
-        flush()
+        frame, flush = make_pipeline(a.gather == "u8")
+
+    def sync(flush_now=None):
+        (flush_now or flush)()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -249,8 +254,22 @@ def main():
         st = fly.stats()
         del scratch
 
+    # ---- the same frames with the other payload of the gather (floats if bytes were timed above, or the reverse)
+    other_elapsed = None
+    if piped:
+        turn[0] = 0
+        other_frame, other_flush = make_pipeline(a.gather != "u8")
+        for _ in range(a.warmup):
+            other_frame(timed)
+        sync(other_flush)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            other_frame(timed)
+        sync(other_flush)
+        other_elapsed = time.perf_counter() - t0
+
     # ---- reduce over ranks: slowest rank's time, all ranks' rays
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t_el = torch.tensor([elapsed, other_elapsed or 0.0], dtype=torch.float64, device=dev)
     rays = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_bounce], dtype=torch.float64, device=dev)
     kern = torch.tensor([st.ms_trace, st.ms_shadow, st.launches_trace, st.launches_shadow, st.ms_compact, st.ms_shade, st.ms_frames,
                          st.ms_raster, st.launches_raster], dtype=torch.float64, device=dev)
@@ -264,7 +283,7 @@ def main():
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
     else:
         kmax = kern
-    elapsed = float(t_el.item())
+    elapsed, other_elapsed = float(t_el[0].item()), float(t_el[1].item())
     rays_frame = float(rays.sum().item())
     ms_per_step = elapsed / a.steps * 1e3
     value = rays_frame * a.steps / elapsed / 1e6
@@ -361,7 +380,10 @@ def main():
             host_ms = (time.perf_counter() - t0) / 5 * 1e3
             out["host_boundary"] = {"ms_per_frame": round(host_ms, 3), "Mrays_per_s": round(rays_frame / host_ms / 1e3, 1),
                                     "note": "rtamd_render with host output buffers, PCIe download included"}
-        if world > 1:
+        if piped:
+            out["other_gather"] = {"payload": "float32" if a.gather == "u8" else "8-bit (PPM pixels)",
+                                   "ms_per_step": round(other_elapsed / a.steps * 1e3, 4),
+                                   "value": round(rays_frame * a.steps / other_elapsed / 1e6, 3)}
             # the whole frame of the SAME workload on this one GPU, no exchange: the single-GPU figure that the
             # N-GPU value above is to be compared with (the N = 1 default of this script is another workload)
             whole = tiles.part_params(base, 1, 0)
