@@ -1,4 +1,4 @@
-"""The five BASELINE configurations as concrete inputs (synthetic where the reference's own files are
+"""The five benchmark configurations as concrete inputs (synthetic where the reference's own files are
 missing from its snapshot).
 
 Every workload is a dict: mesh arrays (file coordinates, as an OBJ would give them), materials,

@@ -11,8 +11,8 @@ import raytracer_amd as R
 SCENES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scenes")
 
 # Tolerances of the parity gate.
-FACE_ID_MIN_MATCH = 0.999   # share of primary rays with the same face id (north star)
-PIXEL_TOL = 1e-3            # per-channel colour error on pixels whose face ids agree (north star)
+FACE_ID_MIN_MATCH = 0.999   # share of primary rays with the same face id (acceptance bar)
+PIXEL_TOL = 1e-3            # per-channel colour error on pixels whose face ids agree (acceptance bar)
 
 
 def scene_path(name):

@@ -1,9 +1,9 @@
 """Parity of the HIP path (through the C ABI) with the CPU oracle.  Run on the GPU box: -m gpu.
 
 The bar: the primary face-id plane must agree with the oracle on every pixel the oracle did not flag as
-NaN-dependent (the north star asks for >= 99.9 %; these scenes give 100 %), the ray counts (primary,
+NaN-dependent (the acceptance bar is >= 99.9 %; these scenes give 100 %), the ray counts (primary,
 shadow, bounce) must be identical -- they are sums over every hit of the whole ray tree, so they check
-the secondary rays too -- and colours must agree within PIXEL_TOL = 1e-3 per channel (the north star's
+the secondary rays too -- and colours must agree within PIXEL_TOL = 1e-3 per channel (the acceptance
 tolerance; observed differences are a few 1e-8, from powf)."""
 import ctypes as C
 import glob
@@ -410,7 +410,7 @@ def test_raytrace_scene_writes_the_reference_ppm(tmp_path):
     assert diff.max() <= 1  # a last-bit colour difference can cross an integer boundary of 255*c
 
 
-# ---- BASELINE configurations at full size: properties that do not need the oracle on every pixel
+# ---- the benchmark configurations at full size: properties that do not need the oracle on every pixel
 
 def _rows_sample_parity(wname, rows_step, tol_pixels=0):
     """Full-size frame on the GPU; the oracle renders every rows_step-th row of it."""
