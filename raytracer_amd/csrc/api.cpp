@@ -472,6 +472,11 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     s->ds.grid_cells = (const int32_t *)s->d_grid_cells;
     s->ds.grid_entries = (const int2 *)s->d_grid_entries;
     s->ds.use_grids = grids.usable ? 1 : 0;
+    for (int ci = 0; ci < 4; ++ci) {
+        const int32_t c = bvh.nodes4[0].child[ci];
+        for (int gk = 0; gk < 4; ++gk) // a leaf directly under the root goes to one lane
+            s->ds.start16[4 * ci + gk] = c >= 0 ? bvh.nodes4[(size_t)c].child[gk] : (gk == 0 ? c : 0x7fffffff);
+    }
     s->bin_primary = !(build && build->primary_rays == RTAMD_PRIMARY_RAYS_TREE);
     s->bin_always = build && build->primary_rays == RTAMD_PRIMARY_RAYS_BINS;
     s->info.shadow_grid_entries = grids.usable ? (uint64_t)grids.entries.size() : 0;

@@ -28,6 +28,8 @@ struct DeviceScene {
     const int32_t *grid_cells;    // cell-start array of all grids
     const int2 *grid_entries;     // (TriRecord index, zmax bits)
     int32_t use_grids;
+    // the (up to) sixteen grandchildren of the root, where the lanes of a shared ray start (0x7fffffff: none)
+    int32_t start16[16];
 };
 
 // Per-launch constants (camera + the reference's macros).
