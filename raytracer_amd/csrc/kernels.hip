@@ -209,10 +209,13 @@ constexpr int kMinGroupShift = RT_MIN_GROUP_SHIFT; // narrowest group: 16 rays
 #ifndef RT_SHADOW_SPLIT_BELOW
 #define RT_SHADOW_SPLIT_BELOW (1 << 16)
 #endif
+#ifndef RT_SPLIT_LANES_SHIFT
+#define RT_SPLIT_LANES_SHIFT 2
+#endif
 #ifndef RT_SHADOW_SPLIT_SHIFT
 #define RT_SHADOW_SPLIT_SHIFT 4
 #endif
-constexpr int kSplitRaysBelow = RT_SPLIT_RAYS_BELOW;           // bounce launches below this many rays put sixteen lanes on a ray
+constexpr int kSplitRaysBelow = RT_SPLIT_RAYS_BELOW;           // bounce launches below this many rays put several lanes on a ray
 constexpr int kFullChipWaves = 8192;               // a launch with fewer groups leaves SIMDs of the 256 CUs idle
 
 // Entry `sp` of the traversal stack.  The empty asm keeps the two loads in separate blocks: merged into one
@@ -262,19 +265,22 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
     if (MODE == kQueue) // measured: no gain for shadow rays, whose groups already share origin region and direction
         while (shift > kMinGroupShift && (rays >> shift) < kFullChipWaves) --shift;
     // Bounce launches smaller still are bound by their single slowest ray (a ray skimming a surface meets a
-    // hundred nodes and as many faces, one dependent fetch after the other).  Sixteen lanes then share one ray:
-    // each starts at one of the (up to) sixteen grandchildren of the root, the lanes prune against the nearest
-    // hit any of them has found so far, and the sixteen results are merged under the reference's tie rule.
+    // hundred nodes and as many faces, one dependent fetch after the other).  Four lanes then share one ray:
+    // the (up to) sixteen grandchildren of the root are dealt to them, one to start from and the rest on the
+    // stack, the lanes prune against the nearest hit any of them has found so far, and their results are merged
+    // under the reference's tie rule.  (Sixteen lanes shorten a lone frame's chain as well, 0.179 vs 0.166 ms for
+    // 152 K rays, but cost a tenth of the throughput once frames overlap: every lane pays a wave's fixed fetches.)
     const bool split = MODE == kQueue && rays < kSplitRaysBelow;
-    __shared__ int s_cut[4]; // per ray of the wave: bits of the nearest accepted distance
-    if (split) shift = 2;
+    constexpr int kRayLanesShift = RT_SPLIT_LANES_SHIFT, kRayLanes = 1 << kRayLanesShift; // lanes that share one ray
+    __shared__ int s_cut[64 >> kRayLanesShift]; // per ray of the wave: bits of the nearest accepted distance
+    if (split) shift = 6 - kRayLanesShift;
     const int width = split ? 64 : 1 << shift;
     const int per_sample = MODE == kShadow ? (nhits + width - 1) >> shift : 0; // hit chunks
     const int ngroups = MODE == kShadow ? per_sample * nshadow : (rays + (1 << shift) - 1) >> shift;
     unsigned w_box = 0, w_plane = 0, w_edge = 0;
 
     for (int group = (int)blockIdx.x; group < ngroups; group += (int)gridDim.x) {
-        const int item = split ? (group << 2) + (lane >> 4) : (group << shift) + lane;
+        const int item = split ? (group << (6 - kRayLanesShift)) + (lane >> kRayLanesShift) : (group << shift) + lane;
 
         V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
         bool valid = lane < width;
@@ -338,10 +344,20 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
         if (ANY && best_tri == -1) node = kSentinel; // a sphere already blocks the sample
         // far limit, widened so that equal and last-bit-different distances are still visited
         float tlimit = ANY ? FLT_MAX : tbest * 1.000001f;
-        int *const cut_bits = s_cut + (lane >> 4);
+        int *const cut_bits = s_cut + (lane >> kRayLanesShift);
         if (split) {
-            const int sub = lane & 15;
+            const int sub = lane & (kRayLanesShift ? kRayLanes - 1 : 0);
             node = sc.start16[sub]; // read off the tree once at scene creation: two dependent fetches less per wave
+            for (int more = sub + kRayLanes; more < 16; more += kRayLanes) { // fewer lanes than start nodes: the rest waits on the stack
+                const int extra = sc.start16[more];
+                if (extra == kSentinel) continue;
+                if (node == kSentinel) {
+                    node = extra;
+                } else {
+                    stack_write(stack, deep, sp, extra);
+                    ++sp;
+                }
+            }
             if (sub == 0) *cut_bits = __float_as_int(tbest);
         }
 
@@ -481,13 +497,13 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
             }
         }
 
-        if (split) { // merge the sixteen lanes of the ray: nearest wins, equal distances go to the later face (:760)
-            for (int m = 1; m < 16; m <<= 1) {
+        if (split) { // merge the lanes of the ray: nearest wins, equal distances go to the later face (:760)
+            for (int m = 1; m < kRayLanes; m <<= 1) {
                 const float ot = __shfl_xor(tbest, m, 64);
                 const int orank = __shfl_xor(best_rank, m, 64), otri = __shfl_xor(best_tri, m, 64);
                 if (ot < tbest || (ot == tbest && orank > best_rank)) tbest = ot, best_rank = orank, best_tri = otri;
             }
-            if ((lane & 15) != 0) continue;
+            if ((lane & (kRayLanes - 1)) != 0) continue;
         }
         if (ANY) {
             ws.clear[depth & 1][out_index] = best_tri == -2 ? 1 : 0;
