@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -104,7 +105,11 @@ void build_one(const FlatBvh &bvh, const float *dir, double scale, OneGrid &g, i
     }
     if (n == 0) gu0 = gv0 = 0.0, gu1 = gv1 = 1.0;
     const double extent = std::max(std::max(gu1 - gu0, gv1 - gv0), 1e-30);
-    int res = (int)std::lround(std::sqrt(2.0 * (double)std::max<size_t>(n, 1)));
+    // Cells per face.  The kernel is bound by fetching the lists, and finer cells mean shorter lists (fewer faces
+    // whose box merely touches the cell): 4 cells per face against 2 take 6-10 % off the shadow rays for 1.7x the
+    // entries; 8 gain little more and cost the build and the caches.
+    static const double density = std::getenv("RTAMD_GRID_DENSITY") ? std::atof(std::getenv("RTAMD_GRID_DENSITY")) : 4.0;
+    int res = (int)std::lround(std::sqrt(density * (double)std::max<size_t>(n, 1)));
     res = std::min(std::max(res, 16), 4096);
 
     for (;; res /= 2) { // halve the resolution until the lists fit
