@@ -384,10 +384,14 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     if (!(build && build->shadow_rays == RTAMD_SHADOW_RAYS_TREE))
         build_shadow_grids(bvh, d->light_samples, d->num_lights * d->samples_per_light, grids);
     const double tg = now_ms();
-    std::vector<ShadeRecord> shade((size_t)d->num_faces);
-    auto fill_shade = [&](int32_t f0, int32_t f1) {
-        for (int32_t f = f0; f < f1; ++f) {
-            ShadeRecord &r = shade[f];
+    // one record per TriRecord, in the same (leaf) order: hits that are neighbours in space read neighbouring records,
+    // and the shading kernels need no detour over the face index
+    const int32_t num_records = (int32_t)bvh.tris.size();
+    std::vector<ShadeRecord> shade((size_t)num_records);
+    auto fill_shade = [&](int32_t i0, int32_t i1) {
+        for (int32_t i = i0; i < i1; ++i) {
+            const int32_t f = bvh.tris[(size_t)i].face;
+            ShadeRecord &r = shade[(size_t)i];
             std::memset(&r, 0, sizeof r);
             const int32_t *id = d->face_vertex_ids + 3 * (size_t)f;
             std::memcpy(r.v0, d->vertices + 3 * (size_t)id[0], 12);
@@ -401,13 +405,13 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
             if (textured) std::memcpy(r.tc, d->face_texcoords + 6 * (size_t)f, 24);
         }
     };
-    if (d->num_faces < (1 << 16)) {
-        fill_shade(0, d->num_faces);
+    if (num_records < (1 << 16)) {
+        fill_shade(0, num_records);
     } else {
         const int workers = 8;
         std::vector<std::thread> pool;
         for (int w = 0; w < workers; ++w)
-            pool.emplace_back(fill_shade, (int32_t)((int64_t)d->num_faces * w / workers), (int32_t)((int64_t)d->num_faces * (w + 1) / workers));
+            pool.emplace_back(fill_shade, (int32_t)((int64_t)num_records * w / workers), (int32_t)((int64_t)num_records * (w + 1) / workers));
         for (std::thread &t : pool) t.join();
     }
     const double t1 = now_ms();

@@ -49,7 +49,7 @@ struct alignas(64) TriRecord {
     int32_t pad;
 };
 
-// 128 B, indexed by the caller's face index.  What shadeOffFace reads (src/flyscene.cpp:469-502).
+// 128 B, one per TriRecord and in the same order.  What shadeOffFace reads (src/flyscene.cpp:469-502).
 struct alignas(128) ShadeRecord {
     float v0[3], v1[3], v2[3];
     float n0[3], n1[3], n2[3];

@@ -866,8 +866,7 @@ __global__ __launch_bounds__(256) void compact_kernel(DeviceScene sc, FrameConst
         // does this hit reflect?  src/flyscene.cpp:617-632 (a sphere ends the path, :618-621)
         bool go = false;
         if (spawn && hit && tri >= 0) {
-            const int face = __float_as_int(sc.tris[tri * 4 + 1].w);
-            const int mat = __float_as_int(sc.shade[face * kShadeRecordQuads + 5].y);
+            const int mat = __float_as_int(sc.shade[tri * kShadeRecordQuads + 5].y);
             if (mat >= 0 && mat < sc.num_materials) {
                 const float *mp = sc.materials + kMaterialFloats * mat;
                 go = mp[6] > fc.refl_thresh || mp[7] > fc.refl_thresh || mp[8] > fc.refl_thresh; // :631-632
@@ -937,8 +936,7 @@ __global__ __launch_bounds__(256) void compact_kernel(DeviceScene sc, FrameConst
         }
         const V3 hp = o + t * d; // hitPoint, :709,771
         if (go) {
-            const int face = __float_as_int(sc.tris[tri * 4 + 1].w);
-            const float4 s4 = sc.shade[face * kShadeRecordQuads + 4], s5 = sc.shade[face * kShadeRecordQuads + 5];
+            const float4 s4 = sc.shade[tri * kShadeRecordQuads + 4], s5 = sc.shade[tri * kShadeRecordQuads + 5];
             const V3 fn = mk(s4.z, s4.w, s5.x);
             const V3 refl = normalized(d - (2 * dot(d, fn)) * fn); // :785 then :635
             const V3 no = hp + fc.bounce_off * refl;               // :636
@@ -1016,9 +1014,8 @@ __global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, FrameConst f
     if (tri < 0) {
         local = mk(0.7f, 0.9f, 0.0f); // sphere, :463-465
     } else {
-        const int face = __float_as_int(sc.tris[tri * 4 + 1].w);
-        const float4 s0 = sc.shade[face * kShadeRecordQuads + 0], s1 = sc.shade[face * kShadeRecordQuads + 1], s2 = sc.shade[face * kShadeRecordQuads + 2];
-        const float4 s3 = sc.shade[face * kShadeRecordQuads + 3], s4 = sc.shade[face * kShadeRecordQuads + 4], s5 = sc.shade[face * kShadeRecordQuads + 5];
+        const float4 s0 = sc.shade[tri * kShadeRecordQuads + 0], s1 = sc.shade[tri * kShadeRecordQuads + 1], s2 = sc.shade[tri * kShadeRecordQuads + 2];
+        const float4 s3 = sc.shade[tri * kShadeRecordQuads + 3], s4 = sc.shade[tri * kShadeRecordQuads + 4], s5 = sc.shade[tri * kShadeRecordQuads + 5];
         const V3 v0 = mk(s0.x, s0.y, s0.z), v1 = mk(s0.w, s1.x, s1.y), v2 = mk(s1.z, s1.w, s2.x);
         const V3 n0 = mk(s2.y, s2.z, s2.w), n1 = mk(s3.x, s3.y, s3.z), n2 = mk(s3.w, s4.x, s4.y);
         const int mat = __float_as_int(s5.y);
@@ -1041,7 +1038,7 @@ __global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, FrameConst f
             V3 albedo = kd;
             const int tex = sc.num_textures > 0 ? __float_as_int(mp[10]) : -1;
             if (tex >= 0) {
-                const float4 s6 = sc.shade[face * kShadeRecordQuads + 6];
+                const float4 s6 = sc.shade[tri * kShadeRecordQuads + 6];
                 const float u = (a12 * s5.z + a02 * s6.x) + a01 * s6.z;
                 const float v = (a12 * s5.w + a02 * s6.y) + a01 * s6.w;
                 const int first = sc.tex_info[4 * tex], w = sc.tex_info[4 * tex + 1], h = sc.tex_info[4 * tex + 2];
