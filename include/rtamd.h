@@ -95,7 +95,8 @@ typedef struct {
 /* Who builds the hierarchy that replaces boundingBox::splitBox (src/boundingBox.h:69-194).  Images do not
  * depend on the choice; only the time to build and the time per frame do. */
 #define RTAMD_BUILDER_HOST_SAH 0    /* binned surface-area heuristic on the host: best tree, seconds for 10^6 faces */
-#define RTAMD_BUILDER_DEVICE_LBVH 1 /* Morton-order radix tree built on the GPU: milliseconds, somewhat slower rays;
+#define RTAMD_BUILDER_DEVICE_LBVH 1 /* Morton-order radix tree and the shadow-ray grids built on the GPU: milliseconds,
+                                       somewhat slower bounce rays;
                                        falls back to the host builder when it does not apply (rtamd_scene_info::builder) */
 
 typedef struct {

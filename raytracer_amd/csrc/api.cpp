@@ -380,9 +380,12 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
         return fail(RTAMD_ERR_LIMIT, "BVH needs %d traversal stack entries, the kernels hold %d", bvh.stack_need, kStackEntries);
     }
     const bool textured = d->num_textures > 0 && d->face_texcoords && d->material_textures && d->textures;
+    // The grids follow the hierarchy: built on the device when that was (after the records are uploaded, below),
+    // on the host otherwise, or when the device build does not apply.
     ShadowGrids grids;
-    if (!(build && build->shadow_rays == RTAMD_SHADOW_RAYS_TREE))
-        build_shadow_grids(bvh, d->light_samples, d->num_lights * d->samples_per_light, grids);
+    const bool want_grids = !(build && build->shadow_rays == RTAMD_SHADOW_RAYS_TREE);
+    bool grids_on_device = want_grids && builder_used == RTAMD_BUILDER_DEVICE_LBVH;
+    if (want_grids && !grids_on_device) build_shadow_grids(bvh, d->light_samples, d->num_lights * d->samples_per_light, grids);
     const double tg = now_ms();
     // one record per TriRecord, in the same (leaf) order: hits that are neighbours in space read neighbouring records,
     // and the shading kernels need no detour over the face index
@@ -453,9 +456,27 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     if (rc == RTAMD_OK) rc = upload(&s->d_spheres, spheres, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_texels, texels, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_tex_info, tex_info, &bytes);
-    if (rc == RTAMD_OK) rc = upload(&s->d_grid_headers, grids.headers, &bytes);
-    if (rc == RTAMD_OK) rc = upload(&s->d_grid_cells, grids.cell_start, &bytes);
-    if (rc == RTAMD_OK) rc = upload(&s->d_grid_entries, grids.entries, &bytes);
+    DeviceShadowGrids dgrids;
+    double grid_ms = 0.0;
+    if (rc == RTAMD_OK && grids_on_device) {
+        const double tg0 = now_ms();
+        std::string why;
+        if (build_shadow_grids_device(bvh.tris, s->d_tris, d->light_samples, d->num_lights * d->samples_per_light, shadow_grid_density(), dgrids, why)) {
+            s->d_grid_cells = dgrids.d_cell_start, s->d_grid_entries = dgrids.d_entries;
+            bytes += dgrids.num_cells * 4 + dgrids.num_entries * sizeof(ShadowGridEntry);
+            rc = upload(&s->d_grid_headers, dgrids.headers, &bytes);
+        } else {
+            grids_on_device = false;
+            build_shadow_grids(bvh, d->light_samples, d->num_lights * d->samples_per_light, grids);
+        }
+        grid_ms = now_ms() - tg0;
+        if (verbose) std::fprintf(stderr, "rtamd: shadow grids on the %s: %.1f ms%s%s\n", grids_on_device ? "device" : "host", grid_ms, why.empty() ? "" : " -- ", why.c_str());
+    }
+    if (!grids_on_device) {
+        if (rc == RTAMD_OK) rc = upload(&s->d_grid_headers, grids.headers, &bytes);
+        if (rc == RTAMD_OK) rc = upload(&s->d_grid_cells, grids.cell_start, &bytes);
+        if (rc == RTAMD_OK) rc = upload(&s->d_grid_entries, grids.entries, &bytes);
+    }
     if (rc != RTAMD_OK) {
         rtamd_scene_destroy(s);
         return rc;
@@ -475,7 +496,8 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     s->ds.grid_headers = (const float4 *)s->d_grid_headers;
     s->ds.grid_cells = (const int32_t *)s->d_grid_cells;
     s->ds.grid_entries = (const int2 *)s->d_grid_entries;
-    s->ds.use_grids = grids.usable ? 1 : 0;
+    const bool grids_usable = grids_on_device ? dgrids.usable : grids.usable;
+    s->ds.use_grids = grids_usable ? 1 : 0;
     for (int ci = 0; ci < 4; ++ci) {
         const int32_t c = bvh.nodes4[0].child[ci];
         for (int gk = 0; gk < 4; ++gk) // a leaf directly under the root goes to one lane
@@ -483,7 +505,7 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     }
     s->bin_primary = !(build && build->primary_rays == RTAMD_PRIMARY_RAYS_TREE);
     s->bin_always = build && build->primary_rays == RTAMD_PRIMARY_RAYS_BINS;
-    s->info.shadow_grid_entries = grids.usable ? (uint64_t)grids.entries.size() : 0;
+    s->info.shadow_grid_entries = !grids_usable ? 0 : grids_on_device ? dgrids.num_entries : (uint64_t)grids.entries.size();
     s->ds.num_lights = d->num_lights;
     s->ds.spl = d->samples_per_light;
     s->ds.num_spheres = d->num_spheres;
@@ -497,7 +519,7 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     s->info.depth = bvh.depth4;
     s->info.device = dev;
     s->info.device_bytes = bytes;
-    s->info.build_ms = (float)(t1 - t0);
+    s->info.build_ms = (float)(t1 - t0 + grid_ms);
     s->info.builder = builder_used;
     s->info.hierarchy_ms = (float)(th1 - th0);
     s->info.upload_ms = (float)(t2 - t1);

@@ -108,7 +108,7 @@ void build_one(const FlatBvh &bvh, const float *dir, double scale, OneGrid &g, i
     // Cells per face.  The kernel is bound by fetching the lists, and finer cells mean shorter lists (fewer faces
     // whose box merely touches the cell): 4 cells per face against 2 take 6-10 % off the shadow rays for 1.7x the
     // entries; 8 gain little more and cost the build and the caches.
-    static const double density = std::getenv("RTAMD_GRID_DENSITY") ? std::atof(std::getenv("RTAMD_GRID_DENSITY")) : 4.0;
+    const double density = shadow_grid_density();
     int res = (int)std::lround(std::sqrt(density * (double)std::max<size_t>(n, 1)));
     res = std::min(std::max(res, 16), 4096);
 
@@ -170,6 +170,11 @@ void build_one(const FlatBvh &bvh, const float *dir, double scale, OneGrid &g, i
 }
 
 } // namespace
+
+double shadow_grid_density() {
+    static const double density = std::getenv("RTAMD_GRID_DENSITY") ? std::atof(std::getenv("RTAMD_GRID_DENSITY")) : 4.0;
+    return density > 0.0 ? density : 4.0;
+}
 
 void build_shadow_grids(const FlatBvh &bvh, const float *samples, int num_samples, ShadowGrids &out) {
     out = ShadowGrids();

@@ -11,6 +11,7 @@
 // tree walk gives.
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "bvh.hpp"
@@ -39,6 +40,19 @@ struct ShadowGrids {
     std::vector<int32_t> cell_start; // absolute indices into `entries`
     std::vector<ShadowGridEntry> entries;
 };
+
+// The same grids built on the GPU (grid_build.hip): arrays stay in device memory, owned by the caller afterwards.
+struct DeviceShadowGrids {
+    bool usable = false;
+    std::vector<ShadowGridHeader> headers;
+    void *d_cell_start = nullptr; // int32, absolute indices into the entries
+    void *d_entries = nullptr;    // ShadowGridEntry
+    uint64_t num_cells = 0, num_entries = 0;
+};
+// tris: host copy of the records d_tris holds on the device.  false (with a reason): build on the host instead.
+bool build_shadow_grids_device(const std::vector<TriRecord> &tris, const void *d_tris, const float *samples, int num_samples, double density,
+                               DeviceShadowGrids &out, std::string &why);
+double shadow_grid_density(); // cells per face
 
 // samples = num_samples * 3 (the light sample positions = shadow ray directions).
 void build_shadow_grids(const FlatBvh &bvh, const float *samples, int num_samples, ShadowGrids &out);

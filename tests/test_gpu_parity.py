@@ -160,6 +160,94 @@ def test_automatic_choice_between_bins_and_tree():
     assert st.primary_path == 1 and 0 < st.bin_entries <= 38 * st.bins_nonempty
 
 
+@pytest.mark.parametrize("name", ["NthTest", "toy_on_plane", "bunny", "reflect_test", "textured_quad", "glass"])
+def test_device_built_hierarchy_gives_the_same_frame(name):
+    """The hierarchy built on the GPU (Morton-order radix tree) replaces the host SAH tree without changing a bit
+    of the frame: every ray kind is sent through it (no bins, no grids) and compared with the default path."""
+    kw = dict(model=scene_path(name), output="")
+    a = R.Flyscene(**kw).initialize(120, 88)
+    b = R.Flyscene(builder=L.BUILDER_DEVICE_LBVH, primary_rays=L.PRIMARY_RAYS_TREE, shadow_rays=L.SHADOW_RAYS_TREE, **kw).initialize(120, 88)
+    c = R.Flyscene(builder=L.BUILDER_DEVICE_LBVH, max_leaf_faces=1, **kw).initialize(120, 88)
+    assert a.info().builder == L.BUILDER_HOST_SAH
+    assert b.info().builder == L.BUILDER_DEVICE_LBVH and c.info().builder == L.BUILDER_DEVICE_LBVH
+    assert b.info().num_device_faces == a.info().num_device_faces
+    # with the device builder the shadow grids are built on the GPU as well: the same (face, cell) pairs as on the host
+    assert c.info().shadow_grid_entries == a.info().shadow_grid_entries > 0 and b.info().shadow_grid_entries == 0
+    for f in (a, b, c):
+        f.camera_translate(1.0, -0.5, 6.0)
+        f.camera_rotate(-0.1, 0.2)
+    ra = a.render()
+    assert (ra["face_id"] >= 0).any() and ra["stats"].rays_shadow > 0
+    for other in (b, c):
+        ro = other.render()
+        assert np.array_equal(ra["face_id"], ro["face_id"])
+        assert np.array_equal(ra["rgb"].view(np.uint32), ro["rgb"].view(np.uint32))
+        sa, so = ra["stats"], ro["stats"]
+        assert (sa.rays_primary, sa.rays_shadow, sa.rays_bounce, sa.hits) == (so.rays_primary, so.rays_shadow, so.rays_bounce, so.hits)
+
+
+def test_device_builder_on_a_large_mesh_and_its_fallback():
+    import torch
+
+    w = workloads.get("field2_mirrors_small")
+    frames = []
+    for build in (dict(), dict(builder=L.BUILDER_DEVICE_LBVH)):
+        fly, params, cam = workloads.make_flyscene(w, **build)
+        rgb = torch.zeros((w["height"], w["width"], 3), dtype=torch.float32, device="cuda")
+        fid = torch.zeros((w["height"], w["width"]), dtype=torch.int32, device="cuda")
+        fly.render_device(rgb, fid, camera=cam)
+        torch.cuda.synchronize()
+        frames.append((fly.info(), rgb.cpu().numpy(), fid.cpu().numpy(), fly.stats()))
+    (ia, rgb_a, fid_a, sa), (ib, rgb_b, fid_b, sb) = frames
+    assert ia.builder == L.BUILDER_HOST_SAH and ib.builder == L.BUILDER_DEVICE_LBVH and ib.num_device_faces == ia.num_device_faces
+    assert ib.hierarchy_ms < ia.hierarchy_ms
+    assert ib.shadow_grid_entries == ia.shadow_grid_entries > 0
+    assert np.array_equal(fid_a, fid_b)
+    assert np.array_equal(rgb_a.view(np.uint32), rgb_b.view(np.uint32))
+    assert sa.rays_bounce == sb.rays_bounce > 0 and sa.rays_shadow == sb.rays_shadow
+    # one face: nothing to sort, the host builder takes over and says so
+    one = R.Flyscene(arrays=(np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32), None, np.array([[0, 1, 2]], np.int32),
+                             np.array([0], np.int32), [dict(ka=(0, 0, 0), kd=(1, 0, 0), ks=(0, 0, 0), shininess=1.0)]),
+                     builder=L.BUILDER_DEVICE_LBVH, output="").initialize(32, 32)
+    assert one.info().builder == L.BUILDER_HOST_SAH
+    assert (one.render()["face_id"] >= 0).any()
+
+
+def test_frames_in_flight_on_several_streams():
+    """Every stream a caller renders on gets a workspace of its own: frames enqueued on different streams may run
+    at the same time and still give the frames a single stream gives, also with more streams than workspaces."""
+    import torch
+
+    fly, _ = make_pair("reflect_test", width=160, height=120)
+    cams = []
+    for k in range(6):
+        fly.camera_translate(0.4, -0.2, 1.0)
+        fly.camera_rotate(0.05, -0.03)
+        cams.append(fly.getCamera())
+    shape = (120, 160)
+    want = []
+    for cam in cams:
+        rgb = torch.zeros(shape + (3,), dtype=torch.float32, device="cuda")
+        fid = torch.zeros(shape, dtype=torch.int32, device="cuda")
+        fly.render_device(rgb, fid, camera=cam)
+        torch.cuda.synchronize()
+        want.append((rgb.cpu().numpy(), fid.cpu().numpy()))
+    assert fly.stats().rays_bounce > 0
+    assert not np.array_equal(want[0][1], want[5][1])
+    for nstreams in (2, 3, 6):  # 6 > the four workspaces a scene keeps: the least recently used one changes hands
+        streams = [torch.cuda.Stream() for _ in range(nstreams)]
+        outs = [(torch.zeros(shape + (3,), dtype=torch.float32, device="cuda"), torch.zeros(shape, dtype=torch.int32, device="cuda"))
+                for _ in cams]
+        torch.cuda.synchronize()
+        for rounds in range(3):
+            for k, cam in enumerate(cams):
+                fly.render_device(outs[k][0], outs[k][1], camera=cam, stream=streams[k % nstreams])
+        torch.cuda.synchronize()
+        for k in range(len(cams)):
+            assert np.array_equal(outs[k][1].cpu().numpy(), want[k][1]), (nstreams, k)
+            assert np.array_equal(outs[k][0].cpu().numpy().view(np.uint32), want[k][0].view(np.uint32)), (nstreams, k)
+
+
 def _random_soup(seed):
     """Triangle soup with the cases that decide ties and rejections: coincident faces with different materials
     (the reference keeps the one it meets last), overlapping coplanar faces, zero-area faces, axis-aligned

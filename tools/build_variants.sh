@@ -9,7 +9,7 @@ while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   ( /opt/rocm/bin/hipcc $COMMON --offload-arch=gfx950 $flags -c kernels.hip -o build/var/kernels_$name.o \
       -Rpass-analysis=kernel-resource-usage 2> build/var/res_$name.txt;
-    g++ -shared -fPIC -pthread -o ../lib/variants/librtamd_$name.so build/var/kernels_$name.o build/lbvh.o build/api.o build/bvh.o build/shadow_grid.o build/flyscene_host.o ) &
+    g++ -shared -fPIC -pthread -o ../lib/variants/librtamd_$name.so build/var/kernels_$name.o build/lbvh.o build/grid_build.o build/api.o build/bvh.o build/shadow_grid.o build/flyscene_host.o ) &
 done
 wait
 ls ../lib/variants
