@@ -20,11 +20,13 @@ struct Box3 {
     float lo[3], hi[3];
 };
 
-__device__ __forceinline__ unsigned spread10(unsigned v) { // 10 bits -> every third bit
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
+__device__ __forceinline__ unsigned long long spread21(unsigned long long v) { // 21 bits -> every third bit
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x1f00000000ffffull;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
     return v;
 }
 
@@ -37,19 +39,19 @@ __device__ __forceinline__ Box3 face_box(const TriRecord &t) {
     return b;
 }
 
-__global__ void morton_kernel(const TriRecord *faces, int n, Box3 scene, unsigned *keys, int *values) {
+__global__ void morton_kernel(const TriRecord *faces, int n, Box3 scene, unsigned long long *keys, int *values) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n) return;
     const Box3 b = face_box(faces[i]);
-    unsigned q[3];
+    unsigned long long q[3];
     for (int k = 0; k < 3; ++k) {
         const float ext = scene.hi[k] - scene.lo[k];
         const float c = 0.5f * (b.lo[k] + b.hi[k]);
         float u = ext > 0.0f ? (c - scene.lo[k]) / ext : 0.0f;
-        u = fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
-        q[k] = (unsigned)u;
+        u = fminf(fmaxf(u * 2097152.0f, 0.0f), 2097151.0f); // 21 bits per axis: a face in a large scene still gets a cell of its own
+        q[k] = (unsigned long long)u;
     }
-    keys[i] = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
+    keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
     values[i] = i;
 }
 
@@ -63,16 +65,16 @@ __global__ void gather_kernel(const TriRecord *faces, const int *perm, int n, Tr
 }
 
 // length of the common prefix of keys i and j (ties broken by the position), -1 outside the array
-__device__ __forceinline__ int common_prefix(const unsigned *keys, int n, int i, int j) {
+__device__ __forceinline__ int common_prefix(const unsigned long long *keys, int n, int i, int j) {
     if (j < 0 || j >= n) return -1;
-    const unsigned a = keys[i], b = keys[j];
-    if (a != b) return __clz(a ^ b);
-    return 32 + __clz((unsigned)i ^ (unsigned)j);
+    const unsigned long long a = keys[i], b = keys[j];
+    if (a != b) return __clzll((long long)(a ^ b));
+    return 64 + __clz((unsigned)i ^ (unsigned)j);
 }
 
 // Internal node i of the binary radix tree over the sorted keys: children as references (>= 0 internal node,
 // < 0 leaf ~position), the sorted positions [first, last] it spans, parents of both.
-__global__ void radix_tree_kernel(const unsigned *keys, int n, int *child, int2 *range, int *parent_of_node, int *parent_of_leaf) {
+__global__ void radix_tree_kernel(const unsigned long long *keys, int n, int *child, int2 *range, int *parent_of_node, int *parent_of_leaf) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n - 1) return;
     const int d = common_prefix(keys, n, i, i + 1) - common_prefix(keys, n, i, i - 1) >= 0 ? 1 : -1;
@@ -221,7 +223,7 @@ bool build_lbvh_device(const std::vector<TriRecord> &faces, int max_leaf_faces, 
     const double t0 = now();
     DeviceBuffers buf;
     TriRecord *d_faces = nullptr, *d_sorted = nullptr;
-    unsigned *d_keys = nullptr, *d_keys_sorted = nullptr;
+    unsigned long long *d_keys = nullptr, *d_keys_sorted = nullptr;
     int *d_vals = nullptr, *d_perm = nullptr, *d_child = nullptr, *d_parent_node = nullptr, *d_parent_leaf = nullptr, *d_arrivals = nullptr,
         *d_depth = nullptr;
     Box3 *d_leaf_box = nullptr, *d_node_box = nullptr;
@@ -240,13 +242,13 @@ bool build_lbvh_device(const std::vector<TriRecord> &faces, int max_leaf_faces, 
     const unsigned blocks = (unsigned)((n + 255) / 256);
     morton_kernel<<<blocks, 256>>>(d_faces, n, scene, d_keys, d_vals);
     size_t temp_bytes = 0;
-    LBVH_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_keys, d_keys_sorted, d_vals, d_perm, n, 0, 30));
+    LBVH_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_keys, d_keys_sorted, d_vals, d_perm, n, 0, 63));
     char *d_temp = nullptr;
     if (!buf.get(&d_temp, temp_bytes)) {
         why = "out of device memory";
         return false;
     }
-    LBVH_TRY(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_keys, d_keys_sorted, d_vals, d_perm, n, 0, 30));
+    LBVH_TRY(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_keys, d_keys_sorted, d_vals, d_perm, n, 0, 63));
     gather_kernel<<<blocks, 256>>>(d_faces, d_perm, n, d_sorted, d_leaf_box);
     radix_tree_kernel<<<blocks, 256>>>(d_keys_sorted, n, d_child, d_range, d_parent_node, d_parent_leaf);
     LBVH_TRY(hipMemset(d_arrivals, 0, N * sizeof(int)));
@@ -258,18 +260,31 @@ bool build_lbvh_device(const std::vector<TriRecord> &faces, int max_leaf_faces, 
     int depth2 = 0;
     LBVH_TRY(hipMemcpy(&depth2, d_depth, sizeof(int), hipMemcpyDeviceToHost));
     const double t3 = now();
-    // a four-way node spans two binary levels; a walk holds at most three waiting siblings per level
-    const int depth4 = (depth2 + 1) / 2;
-    const int need = 3 * depth4;
-    if (need > kStackEntries) {
-        why = "radix tree of depth " + std::to_string(depth2) + " needs " + std::to_string(need) + " stack entries";
-        return false;
-    }
+    const int depth4 = (depth2 + 1) / 2; // a four-way node spans two binary levels
     out.nodes.clear();
     out.nodes4.resize(N - 1);
     out.tris.resize(N);
     LBVH_TRY(hipMemcpy(out.nodes4.data(), d_nodes4, (N - 1) * sizeof(Bvh4Node), hipMemcpyDeviceToHost));
     LBVH_TRY(hipMemcpy(out.tris.data(), d_sorted, N * sizeof(TriRecord), hipMemcpyDeviceToHost));
+    // Most entries a depth-first walk can hold: at a node with k children one is entered and k - 1 wait, whatever
+    // the order; the deepest such chain decides.  (Long Morton codes make deep but thin trees: three entries per
+    // level, the bound without looking, would turn many of them down.)
+    struct Need {
+        const std::vector<Bvh4Node> &nodes;
+        int of(int32_t node, int level) const {
+            if (level > 128) return 1 << 20; // not a tree this walk can take
+            const Bvh4Node &nd = nodes[(size_t)node];
+            int below = 0;
+            for (int c = 0; c < nd.num_children; ++c)
+                if (nd.child[c] >= 0) below = std::max(below, of(nd.child[c], level + 1));
+            return std::max(nd.num_children - 1, 0) + below;
+        }
+    };
+    const int need = Need{out.nodes4}.of(0, 0);
+    if (need > kStackEntries) {
+        why = "radix tree of depth " + std::to_string(depth2) + " needs " + std::to_string(need) + " stack entries";
+        return false;
+    }
     if (verbose)
         std::fprintf(stderr, "rtamd: device builder, %d faces: allocate %.2f ms, upload %.2f ms, kernels %.2f ms, download %.2f ms\n", n, t1 - t0,
                      t2 - t1, t3 - t2, now() - t3);
