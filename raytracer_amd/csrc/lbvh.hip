@@ -142,16 +142,30 @@ __global__ void collapse_kernel(int n, int max_leaf, const int *child, const int
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n - 1) return;
     auto small = [&](int r) { return r >= 0 && range[r].y - range[r].x < max_leaf; };
+    // Start from the two children and, twice, replace the expandable child of largest surface area by ITS two
+    // children: the large boxes are the ones a ray is likely to enter anyway, so opening them here saves a step.
+    // (Any binary node may so become a child of a four-way node; every binary node has a four-way node written.)
+    auto expandable = [&](int r) { return r >= 0 && !small(r); };
+    auto area = [&](int r) {
+        const Box3 &b = node_box[r];
+        const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
     int refs[4];
-    int k = 0;
-    for (int side = 0; side < 2; ++side) {
-        const int c = child[2 * i + side];
-        if (c >= 0 && !small(c)) {
-            refs[k++] = child[2 * c];
-            refs[k++] = child[2 * c + 1];
-        } else {
-            refs[k++] = c;
-        }
+    int k = 2;
+    refs[0] = child[2 * i], refs[1] = child[2 * i + 1];
+    while (k < 4) {
+        int pick = -1;
+        float best = -1.0f;
+        for (int s = 0; s < k; ++s)
+            if (expandable(refs[s])) {
+                const float a = area(refs[s]);
+                if (a > best) best = a, pick = s;
+            }
+        if (pick < 0) break;
+        const int c = refs[pick];
+        refs[pick] = child[2 * c];
+        refs[k++] = child[2 * c + 1];
     }
     Bvh4Node nd;
     for (int s = 0; s < 4; ++s) {
