@@ -274,7 +274,6 @@ bool build_lbvh_device(const std::vector<TriRecord> &faces, int max_leaf_faces, 
     int depth2 = 0;
     LBVH_TRY(hipMemcpy(&depth2, d_depth, sizeof(int), hipMemcpyDeviceToHost));
     const double t3 = now();
-    const int depth4 = (depth2 + 1) / 2; // a four-way node spans two binary levels
     out.nodes.clear();
     out.nodes4.resize(N - 1);
     out.tris.resize(N);
@@ -285,8 +284,10 @@ bool build_lbvh_device(const std::vector<TriRecord> &faces, int max_leaf_faces, 
     // level, the bound without looking, would turn many of them down.)
     struct Need {
         const std::vector<Bvh4Node> &nodes;
-        int of(int32_t node, int level) const {
+        int deepest = 0;
+        int of(int32_t node, int level) {
             if (level > 128) return 1 << 20; // not a tree this walk can take
+            deepest = std::max(deepest, level + 1);
             const Bvh4Node &nd = nodes[(size_t)node];
             int below = 0;
             for (int c = 0; c < nd.num_children; ++c)
@@ -294,7 +295,8 @@ bool build_lbvh_device(const std::vector<TriRecord> &faces, int max_leaf_faces, 
             return std::max(nd.num_children - 1, 0) + below;
         }
     };
-    const int need = Need{out.nodes4}.of(0, 0);
+    Need walk{out.nodes4};
+    const int need = walk.of(0, 0);
     if (need > kStackEntries) {
         why = "radix tree of depth " + std::to_string(depth2) + " needs " + std::to_string(need) + " stack entries";
         return false;
@@ -304,7 +306,7 @@ bool build_lbvh_device(const std::vector<TriRecord> &faces, int max_leaf_faces, 
                      t2 - t1, t3 - t2, now() - t3);
     out.num_leaves = n;
     out.depth = depth2;
-    out.depth4 = depth4;
+    out.depth4 = walk.deepest;
     out.stack_need = need;
     out.num_device_faces = n;
     return true;
