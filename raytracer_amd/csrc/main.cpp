@@ -3,12 +3,21 @@
 // calls Flyscene::raytraceScene() once and exits.
 //
 //   raytrace [--obj PATH] [--size WxH] [--out FILE.ppm] [--max-reflections N] [--ssaa N]
-//            [--hard-shadows-only] [--light X,Y,Z]... [--move DX,DY,DZ]
+//            [--hard-shadows-only] [--light X,Y,Z]... [--move DX,DY,DZ] [--device-builder]
+//            [--frames N [--in-flight F]]
+//
+// --frames N renders N more views of a slow orbit straight into device buffers, F of them enqueued at a time, each
+// on a HIP stream of its own (rtamd_render_device keeps one workspace per stream): the way a host that renders a
+// sequence gets the frames to overlap on the GPU.
+#include <hip/hip_runtime.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/rtamd_flyscene.h"
 #include "flyscene_host.hpp"
@@ -16,7 +25,7 @@
 int main(int argc, char **argv) {
     rtamd::Flyscene fly;
     int width = 1000, height = 1000; // src/main.cpp:9-10
-    int max_reflections = -1, ssaa = -1;
+    int max_reflections = -1, ssaa = -1, frames = 0, in_flight = 4;
     float move[3] = {0, 0, 0};
     bool moved = false;
     for (int i = 1; i < argc; ++i) {
@@ -39,6 +48,12 @@ int main(int argc, char **argv) {
             if (std::sscanf(next(), "%f,%f,%f", &l.position[0], &l.position[1], &l.position[2]) != 3) return std::fprintf(stderr, "--light X,Y,Z\n"), 2;
             fly.lights.push_back(l);
             fly.lights_defaulted = true; // explicit lights replace the built-in one
+        } else if (a == "--frames") {
+            frames = std::atoi(next());
+        } else if (a == "--in-flight") {
+            in_flight = std::min(std::max(std::atoi(next()), 1), 4);
+        } else if (a == "--device-builder") {
+            fly.build.builder = RTAMD_BUILDER_DEVICE_LBVH;
         } else if (a == "--move") {
             if (std::sscanf(next(), "%f,%f,%f", &move[0], &move[1], &move[2]) != 3) return std::fprintf(stderr, "--move DX,DY,DZ\n"), 2;
             moved = true;
@@ -75,5 +90,34 @@ int main(int argc, char **argv) {
         return 1;
     }
     std::printf("Done! Total time: %.0fms -> %s\n", ms(t1, t2), fly.output_path.c_str());
+    if (frames > 0) {
+        // a sequence: frame k goes to stream k mod F and buffer k mod F, nothing comes back to the host in between
+        std::vector<hipStream_t> streams((size_t)in_flight);
+        std::vector<float *> rgb((size_t)in_flight, nullptr);
+        const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+        for (int k = 0; k < in_flight; ++k)
+            if (hipStreamCreateWithFlags(&streams[(size_t)k], hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&rgb[(size_t)k], bytes) != hipSuccess)
+                return std::fprintf(stderr, "HIP stream or buffer allocation failed\n"), 1;
+        rtamd_stats stats;
+        uint64_t rays = 0;
+        const auto t3 = clk::now();
+        for (int k = 0; k < frames; ++k) {
+            fly.getCamera()->rotate(0.0f, 0.002f); // as dragging the mouse does in the reference's window
+            fly.getCamera()->updateViewMatrix();
+            rtamd_camera cam;
+            fly.getCamera()->fill(cam);
+            rc = rtamd_render_device(fly.scene(), &cam, &fly.params, rgb[(size_t)(k % in_flight)], nullptr, nullptr, streams[(size_t)(k % in_flight)]);
+            if (rc != RTAMD_OK) return std::fprintf(stderr, "frame %d failed (%d): %s\n", k, rc, rtamd_last_error()), 1;
+        }
+        if (rtamd_render_stats(fly.scene(), &stats) != RTAMD_OK) return std::fprintf(stderr, "%s\n", rtamd_last_error()), 1; // waits for all frames
+        const auto t4 = clk::now();
+        rays = stats.rays_primary + stats.rays_shadow + stats.rays_bounce;
+        std::printf("%d frames, %d in flight: %.3f ms per frame, %.0f Mrays/s (last frame: %llu rays)\n", frames, in_flight, ms(t3, t4) / frames,
+                    (double)rays * frames / ms(t3, t4) / 1e3, (unsigned long long)rays);
+        for (int k = 0; k < in_flight; ++k) {
+            (void)hipFree(rgb[(size_t)k]);
+            (void)hipStreamDestroy(streams[(size_t)k]);
+        }
+    }
     return 0;
 }
