@@ -94,11 +94,13 @@ def cpu_baseline(w, cam, budget_s):
     full_rays_est = probe.rays * 64.0
     step = max(1, int(np.ceil(full_rays_est / max(rate * budget_s, 1.0))))
     # a frame shorter than the budget is repeated so that the sample still holds several seconds of CPU work
-    reps = 1 if step > 1 else int(min(500, max(1, budget_s * rate / max(full_rays_est, 1.0))))
+    # (until the budget is used: the probe's few rows spread badly over the threads and underestimate the rate)
     rays = seconds = box = tri = 0.0
-    for _ in range(reps):
+    reps = 0
+    while reps == 0 or (step == 1 and seconds < 0.9 * budget_s and reps < 2000):
         res = orc.render(W, H, camera=oc, planes=False, row_offset=0, row_step=step, **kw)["counters"]
         rays, seconds, box, tri = rays + res.rays, seconds + res.seconds, box + res.box_tests, tri + res.tri_plane
+        reps += 1
     orc.close()
 
     class res:  # totals over the repetitions
