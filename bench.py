@@ -25,6 +25,20 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _hardware_queues():
+    """Frames in flight overlap only while each of their streams has a hardware queue of its own, and the HIP runtime
+    reads GPU_MAX_HW_QUEUES (four by default) once, at its first call: set it before torch loads the runtime.
+    One GPU only: with several, two frames are in flight and the streams in use stay below four anyway."""
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("--hw-queues", type=int, default=8)
+    queues = pre.parse_known_args()[0].hw_queues
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and queues > 0:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(min(queues, 16))
+
+
+_hardware_queues()
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -55,8 +69,10 @@ def parse():
     ap.add_argument("--row-tile", type=int, default=16)
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH: faces per leaf (0 = library default)")
     ap.add_argument("--sah-bins", type=int, default=0, help="BVH: SAH bins (0 = library default)")
-    ap.add_argument("--in-flight", type=int, default=4,
-                    help="frames enqueued at a time, each on a stream of its own (1..4; at most 2 with several GPUs)")
+    ap.add_argument("--in-flight", type=int, default=8,
+                    help="frames enqueued at a time, each on a stream of its own (1..8; at most 2 with several GPUs)")
+    ap.add_argument("--hw-queues", type=int, default=8,
+                    help="one GPU: hardware queues asked of the HIP runtime (GPU_MAX_HW_QUEUES; 0 = leave the environment alone)")
     ap.add_argument("--single-stream", action="store_true",
                     help="keep every frame on its caller's stream (no side streams): with --in-flight 1 every kernel then runs alone, "
                          "which is the mode the per-kernel profile under profiles/ is taken in")
@@ -179,7 +195,7 @@ def main():
     rows = fly.local_rows(mine)
     # Frames in flight: frame k is enqueued on stream k % F into buffer k % F (the scene keeps one workspace per
     # stream), so the small, latency-bound launches of one frame overlap the other frames' work.
-    in_flight = max(1, min(a.in_flight, 4 if world == 1 and not a.force_pipeline else 2))
+    in_flight = max(1, min(a.in_flight, 8 if world == 1 and not a.force_pipeline else 2))
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(in_flight - 1)]
     turn = [0]
     piped = world > 1 or a.force_pipeline

@@ -220,8 +220,8 @@ def test_frames_in_flight_on_several_streams():
 
     fly, _ = make_pair("reflect_test", width=160, height=120)
     cams = []
-    for k in range(6):
-        fly.camera_translate(0.4, -0.2, 1.0)
+    for k in range(10):
+        fly.camera_translate(0.24, -0.12, 0.6)
         fly.camera_rotate(0.05, -0.03)
         cams.append(fly.getCamera())
     shape = (120, 160)
@@ -233,8 +233,8 @@ def test_frames_in_flight_on_several_streams():
         torch.cuda.synchronize()
         want.append((rgb.cpu().numpy(), fid.cpu().numpy()))
     assert fly.stats().rays_bounce > 0
-    assert not np.array_equal(want[0][1], want[5][1])
-    for nstreams in (2, 3, 6):  # 6 > the four workspaces a scene keeps: the least recently used one changes hands
+    assert not np.array_equal(want[0][1], want[9][1])
+    for nstreams in (2, 3, 10):  # 10 > the eight workspaces a scene keeps: the least recently used one changes hands
         streams = [torch.cuda.Stream() for _ in range(nstreams)]
         outs = [(torch.zeros(shape + (3,), dtype=torch.float32, device="cuda"), torch.zeros(shape, dtype=torch.int32, device="cuda"))
                 for _ in cams]
