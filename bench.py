@@ -27,13 +27,13 @@ sys.path.insert(0, ROOT)
 
 
 def _hardware_queues():
-    """Frames in flight overlap only while each of their streams has a hardware queue of its own, and the HIP runtime
-    reads GPU_MAX_HW_QUEUES (four by default) once, at its first call: set it before torch loads the runtime.
-    One GPU only: with several, two frames are in flight and the streams in use stay below four anyway."""
+    """Frames in flight overlap only while each of their streams has a hardware queue of its own (and streams that
+    wait for each other, as the frames and the collective do, must not outnumber the queues at all); the HIP runtime
+    reads GPU_MAX_HW_QUEUES (four by default) once, at its first call: set it before torch loads the runtime."""
     pre = argparse.ArgumentParser(add_help=False)
-    pre.add_argument("--hw-queues", type=int, default=8)
+    pre.add_argument("--hw-queues", type=int, default=16)
     queues = pre.parse_known_args()[0].hw_queues
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and queues > 0:
+    if queues > 0:
         os.environ["GPU_MAX_HW_QUEUES"] = str(min(queues, 16))
 
 
@@ -70,9 +70,10 @@ def parse():
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH: faces per leaf (0 = library default)")
     ap.add_argument("--sah-bins", type=int, default=0, help="BVH: SAH bins (0 = library default)")
     ap.add_argument("--in-flight", type=int, default=8,
-                    help="frames enqueued at a time, each on a stream of its own (1..8; at most 2 with several GPUs)")
-    ap.add_argument("--hw-queues", type=int, default=8,
-                    help="one GPU: hardware queues asked of the HIP runtime (GPU_MAX_HW_QUEUES; 0 = leave the environment alone)")
+                    help="frames enqueued at a time, each on a stream of its own (1..8)")
+    ap.add_argument("--hw-queues", type=int, default=16,
+                    help="hardware queues asked of the HIP runtime (GPU_MAX_HW_QUEUES; 0 = leave the environment alone, and then "
+                         "at most 4 frames in flight on one GPU, 2 with several)")
     ap.add_argument("--single-stream", action="store_true",
                     help="keep every frame on its caller's stream (no side streams): with --in-flight 1 every kernel then runs alone, "
                          "which is the mode the per-kernel profile under profiles/ is taken in")
@@ -195,10 +196,13 @@ def main():
     rows = fly.local_rows(mine)
     # Frames in flight: frame k is enqueued on stream k % F into buffer k % F (the scene keeps one workspace per
     # stream), so the small, latency-bound launches of one frame overlap the other frames' work.
-    in_flight = max(1, min(a.in_flight, 8 if world == 1 and not a.force_pipeline else 2))
+    # With the gather, the frames' streams and the collective's stream wait for each other: together they must stay
+    # below the number of hardware queues, or the waits stall for good.
+    queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    piped = world > 1 or a.force_pipeline
+    in_flight = max(1, min(a.in_flight, 8, max(1, queues - 2) if piped else max(4, queues)))
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(in_flight - 1)]
     turn = [0]
-    piped = world > 1 or a.force_pipeline
     if not piped:
         rgbs = [torch.zeros((max(rows, 1), W, 3), dtype=torch.float32, device=dev) for _ in range(in_flight)]
 
@@ -210,13 +214,14 @@ def main():
         def flush():
             pass
     else:
-        # Two frame buffers: the gather of frame k (RCCL, on its own stream) overlaps the tracing of frame k+1.
+        # A buffer per frame in flight: the gather of frame k (RCCL, on its own stream) overlaps the tracing of the next frames.
         # Every frame is still gathered and put in row order on rank 0 inside the timed region.
         # What is exchanged is what the reference keeps of a frame: the 8-bit pixels of result.ppm, quantised on
         # every rank with the file writer's expression (a quarter of the float framebuffer's bytes); --gather f32
         # sends the floats instead.
         def make_pipeline(as_bytes):
-            pipe = tiles.GatherPipeline(mine, W, 3, dev, dtype=torch.uint8 if as_bytes else torch.float32)
+            pipe = tiles.GatherPipeline(mine, W, 3, dev, dtype=torch.uint8 if as_bytes else torch.float32, depth=in_flight,
+                                        rehearse=world == 1)
             bufs = [torch.zeros((max(rows, 1), W, 3), dtype=torch.float32, device=dev) for _ in range(in_flight)] if as_bytes else None
 
             def frame(p):

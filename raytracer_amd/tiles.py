@@ -111,33 +111,40 @@ def gather_rows(local, params, group=None, dst=0):
 
 
 class GatherPipeline:
-    """Double-buffered frames for a render loop: frame k's gather runs (asynchronously, on the collective's own
-    stream) while frame k+1 is rendered into the other buffer.  Usage, every rank alike:
+    """Frames of a render loop in `depth` buffers: frame k's gather runs (asynchronously, on the collective's own
+    stream) while the next frames are rendered into the other buffers.  Usage, every rank alike:
 
-        pipe = GatherPipeline(params, width, channels, device)
+        pipe = GatherPipeline(params, width, channels, device, depth=D)
         for k in range(frames):
-            buf = pipe.acquire()          # waits (on the stream, not the host) until the gather two frames back is done
+            buf = pipe.acquire()          # waits (on the stream, not the host) until the gather D frames back is done
             render into buf[:local_rows]
             image = pipe.submit()         # starts this frame's gather; returns the frame finished by acquire(), if any
         last = pipe.drain()               # list of the frames still in flight, oldest first
 
-    Images are returned on rank `dst` only (None elsewhere) and lag the submissions by up to two frames.
-    acquire() and submit() take the stream the frame is rendered on (default: the current stream), so that two
-    frames may also be TRACED at the same time, each on a stream of its own: buffer k % 2 goes with stream k % 2."""
+    Images are returned on rank `dst` only (None elsewhere) and lag the submissions by up to `depth` frames.
+    acquire() and submit() take the stream the frame is rendered on (default: the current stream), so that several
+    frames may also be TRACED at the same time, each on a stream of its own: buffer k % D goes with stream k % D.
+    `rehearse` (one process only) puts a device copy on a side stream where the collective would be, with the same
+    waits between the streams: the stream topology of a several-GPU run on one GPU."""
 
-    def __init__(self, params, width, channels, device, dtype=torch.float32, group=None, dst=0):
+    def __init__(self, params, width, channels, device, dtype=torch.float32, group=None, dst=0, depth=2, rehearse=False):
         self.params, self.group, self.dst = params, group, dst
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.depth = max(2, int(depth))
         rows, rows_max, index_padded, _, _ = layout(params, self.world)
         self.rows_max = max(rows_max, 1)
         shape = (self.rows_max, width, channels)
-        self.send = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(2)]
+        self.send = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(self.depth)]
         self.recv = None
         if self.world > 1 and self.rank == dst:
-            self.recv = [torch.empty((self.world,) + shape, dtype=dtype, device=device) for _ in range(2)]
+            self.recv = [torch.empty((self.world,) + shape, dtype=dtype, device=device) for _ in range(self.depth)]
             self.index = index_padded.to(device)
-        self.work = [None, None]
+        self.side = None
+        if self.world == 1 and rehearse:
+            self.side = torch.cuda.Stream(device)
+            self.recv = [torch.empty(shape, dtype=dtype, device=device) for _ in range(self.depth)]
+        self.work = [None] * self.depth
         self.turn = 0
         self.done = None
 
@@ -146,10 +153,10 @@ class GatherPipeline:
         if self.work[b] is None:
             return None
         if self.work[b] is not True:
-            self.work[b].wait()
+            self.work[b].wait()  # a collective's handle or the rehearsal's event: the current stream waits, not the host
         self.work[b] = None
         if self.world == 1:
-            return self.send[b][: self.params.height].clone()
+            return (self.recv if self.side is not None else self.send)[b][: self.params.height].clone()
         if self.rank != self.dst:
             return None
         flat = self.recv[b].view((self.world * self.rows_max,) + tuple(self.send[b].shape[1:]))
@@ -169,14 +176,20 @@ class GatherPipeline:
         with self._on(stream):  # the collective starts behind what this stream has enqueued
             if self.world == 1:
                 self.work[b] = True
+                if self.side is not None:
+                    self.side.wait_stream(torch.cuda.current_stream(self.send[b].device))
+                    with torch.cuda.stream(self.side):
+                        self.recv[b].copy_(self.send[b])
+                        self.work[b] = torch.cuda.Event()
+                        self.work[b].record(self.side)
             elif self.rank == self.dst:
                 self.work[b] = dist.gather(self.send[b], list(self.recv[b].unbind(0)), dst=self.dst, group=self.group, async_op=True)
             else:
                 self.work[b] = dist.gather(self.send[b], None, dst=self.dst, group=self.group, async_op=True)
-        self.turn ^= 1
+        self.turn = (self.turn + 1) % self.depth
         out, self.done = self.done, None
         return out
 
     def drain(self):
-        out = [self._finish(self.turn), self._finish(self.turn ^ 1)]
+        out = [self._finish((self.turn + i) % self.depth) for i in range(self.depth)]
         return [x for x in out if x is not None] if (self.world == 1 or self.rank == self.dst) else []

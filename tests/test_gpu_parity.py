@@ -628,3 +628,40 @@ def test_config4_field_4k_invariants():
     torch.cuda.synchronize()
     img = torch.cat(parts, 0).index_select(0, tiles.row_permutation(base, 8, "cuda"))
     assert torch.equal(img, rgb)
+
+
+@pytest.mark.gpu
+def test_gather_pipeline_rehearsal_on_streams():
+    """The render loop of a several-GPU run on one GPU: frames on two streams, a device copy on a third stream where
+    the collective would be, the same waits between them; every frame comes back, in order."""
+    import torch
+
+    from raytracer_amd import tiles
+
+    fly, _ = make_pair("NthTest", width=96, height=64)
+    p = fly.params_copy(row_tile=16)
+    pipe = tiles.GatherPipeline(p, 96, 3, torch.device("cuda", 0), dtype=torch.uint8, depth=2, rehearse=True)
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream()]
+    rgb = [torch.zeros((64, 96, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+    fly.render_device(rgb[0], params=p)
+    torch.cuda.synchronize()
+    want = np.minimum(255, (255.0 * rgb[0].cpu().numpy()).astype(np.int32)).astype(np.uint8)
+    got = []
+    for k in range(7):
+        s = streams[k % 2]
+        buf = pipe.acquire(s)
+        fly.render_device(rgb[k % 2], params=p, stream=s)
+        tiles.quantize_ppm(rgb[k % 2], buf, 64 * 96 * 3, stream=s)
+        with torch.cuda.stream(s):
+            buf[0, 0, 0] = k  # marks the frame
+        img = pipe.submit(s)
+        if img is not None:
+            got.append(img)
+    got += pipe.drain()
+    torch.cuda.synchronize()
+    assert len(got) == 7
+    for k, img in enumerate(got):
+        img = img.cpu().numpy()
+        assert img[0, 0, 0] == k
+        img[0, 0, 0] = want[0, 0, 0]
+        assert np.array_equal(img, want)

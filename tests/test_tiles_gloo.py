@@ -74,7 +74,7 @@ def test_single_process_path_is_identity():
     assert sorted(idx.tolist()) == list(range(10))
 
 
-def _pipeline_worker(rank, world, port, width, height, tile, frames, q, dtype=torch.float32):
+def _pipeline_worker(rank, world, port, width, height, tile, frames, q, dtype=torch.float32, depth=2):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -83,7 +83,7 @@ def _pipeline_worker(rank, world, port, width, height, tile, frames, q, dtype=to
         mine = tiles.part_params(base, world, rank)
         lib = L.lib()
         rows = lib.rtamd_local_rows(C.byref(mine))
-        pipe = tiles.GatherPipeline(mine, width, 3, "cpu", dtype=dtype)
+        pipe = tiles.GatherPipeline(mine, width, 3, "cpu", dtype=dtype, depth=depth)
         got = []
         for k in range(frames):
             buf = pipe.acquire()
@@ -104,15 +104,17 @@ def _pipeline_worker(rank, world, port, width, height, tile, frames, q, dtype=to
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,height,tile,frames,dtype", [(2, 37, 8, 5, torch.float32), (3, 50, 4, 1, torch.float32),
-                                                            (2, 16, 16, 2, torch.float32), (2, 37, 8, 4, torch.uint8)])
-def test_double_buffered_gather_returns_every_frame_in_order(world, height, tile, frames, dtype):
-    """Also with 8-bit pixels, which is what the ranks exchange by default (the bytes of result.ppm)."""
+@pytest.mark.parametrize("world,height,tile,frames,dtype,depth", [(2, 37, 8, 5, torch.float32, 2), (3, 50, 4, 1, torch.float32, 2),
+                                                                  (2, 16, 16, 2, torch.float32, 2), (2, 37, 8, 4, torch.uint8, 2),
+                                                                  (2, 37, 8, 11, torch.uint8, 4), (2, 21, 4, 3, torch.float32, 8)])
+def test_double_buffered_gather_returns_every_frame_in_order(world, height, tile, frames, dtype, depth):
+    """Also with 8-bit pixels, which is what the ranks exchange by default (the bytes of result.ppm), and with more
+    than two frames in flight (more buffers than frames included)."""
     width = 8
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, width, height, tile, frames, q, dtype)) for r in range(world)]
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, width, height, tile, frames, q, dtype, depth)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)
@@ -128,15 +130,16 @@ def test_double_buffered_gather_returns_every_frame_in_order(world, height, tile
         assert np.array_equal(img[:, 0, 2], ((ys // tile) % world).astype(np.float32))
 
 
-def test_pipeline_single_process():
+@pytest.mark.parametrize("depth,frames", [(2, 3), (3, 7), (8, 5)])
+def test_pipeline_single_process(depth, frames):
     p = R.default_params(4, 6)
-    pipe = tiles.GatherPipeline(p, 4, 3, "cpu")
+    pipe = tiles.GatherPipeline(p, 4, 3, "cpu", depth=depth)
     out = []
-    for k in range(3):
+    for k in range(frames):
         buf = pipe.acquire()
         buf.fill_(k)
         img = pipe.submit()
         if img is not None:
             out.append(img)
     out += pipe.drain()
-    assert [float(x[0, 0, 0]) for x in out] == [0.0, 1.0, 2.0]
+    assert [float(x[0, 0, 0]) for x in out] == [float(k) for k in range(frames)]

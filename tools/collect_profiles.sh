@@ -13,7 +13,7 @@ for wl in bunny_1080p bunny_1000 field_4k; do
 done
 # 2. kernel trace of the default command (eight frames in flight: kernels of different frames overlap) ...
 # (the profiler starts the HIP runtime before bench.py can ask for its hardware queues, so the shell does)
-export GPU_MAX_HW_QUEUES=8
+export GPU_MAX_HW_QUEUES=16
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -- \
   python3 "$ROOT/bench.py" --cpu-seconds 0 > "$OUT/bench_under_rocprof_default.json" 2> "$OUT/trace_default.log" || exit 1
 # 3. ... and with every kernel alone on the GPU: these averages are the ones the roofline's avg_launch_ms must match
