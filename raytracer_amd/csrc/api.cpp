@@ -144,13 +144,18 @@ int ensure_workspace(rtamd_scene *s, FrameSlot &fs, size_t slots, size_t bins_ne
     const size_t bin_capacity = s->bin_primary ? std::min<size_t>(8 * ntris + (1u << 20), (size_t)1 << 30) : 0;
     const size_t bins = s->bin_primary ? bins_needed : 0;
     const size_t bin_bytes = s->bin_primary ? 256 + (2 * bins + 512 + bin_capacity) * 4 + (ntris + 1) * 16 : 0;
-    const size_t total = head + planes * cap * 4 + 2 * nshadow * cap + bin_bytes;
+    const size_t total = head + planes * cap * 4 + 2 * nshadow * cap + bin_bytes + 1024;
     HIP_TRY(hipMalloc(&fs.block, total));
     char *base = (char *)fs.block;
     fs.ws.stage = (StageCounters *)base;
     fs.ws.work = (WorkCounters *)(base + 2048);
     static_assert(sizeof(StageCounters) * kMaxStages <= 2048, "counter block too small");
     char *p = base + head;
+    if (s->bin_primary) { // right behind the counters: one memset clears all three at the start of a frame
+        fs.ws.bin_state = (BinState *)p, p += 256;
+        fs.ws.bin_count = (int32_t *)p, p += (bins + 256) * 4;
+        p = (char *)(((uintptr_t)p + 1023) & ~(uintptr_t)1023);
+    }
     fs.ws.slot_tri = (int32_t *)p, p += cap * 4;
     fs.ws.slot_t = (float *)p, p += cap * 4;
     for (HitList &h : fs.ws.hits) {
@@ -165,8 +170,6 @@ int ensure_workspace(rtamd_scene *s, FrameSlot &fs, size_t slots, size_t bins_ne
     if (s->bin_primary) {
         p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
         fs.ws.big = (int4 *)p, p += (ntris + 1) * 16;
-        fs.ws.bin_state = (BinState *)p, p += 256;
-        fs.ws.bin_count = (int32_t *)p, p += (bins + 256) * 4;
         fs.ws.bin_start = (int32_t *)p, p += (bins + 256) * 4;
         fs.ws.bin_entries = (int32_t *)p, p += bin_capacity * 4;
         fs.ws.bin_capacity = (int32_t)bin_capacity;
@@ -722,7 +725,8 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     auto shadowed = [&](int d) { return fs.sync[(size_t)(3 + 3 * d)]; };
     const bool deep_bg = p->background_deep[0] != 0.0f || p->background_deep[1] != 0.0f || p->background_deep[2] != 0.0f;
 
-    HIP_TRY(hipMemsetAsync(fs.block, 0, 4096, stream));
+    // stage and work counters, and with them the bin counters of the first pass (they lie right behind)
+    HIP_TRY(hipMemsetAsync(fs.block, 0, 4096 + (bins_ok ? 256 + sizeof(int32_t) * (size_t)ws_frame.num_bins : 0), stream));
     int stage = 0;
     for (int xs = 0; xs < S; ++xs)
         for (int ys = 0; ys < S; ++ys) {
@@ -738,7 +742,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
                 // ---- closest hits
                 stream_of_launch = geo;
                 if ((rc = begin(d == 0 && bins_ok ? 6 : 0)) != RTAMD_OK) return rc;
-                if (d == 0 && bins_ok) launch_primary_bins(count, s->ds, fc, ws_frame, s->info.num_device_faces, geo);
+                if (d == 0 && bins_ok) launch_primary_bins(count, s->ds, fc, ws_frame, s->info.num_device_faces, /*cleared=*/stage == 0, geo);
                 launch_walk_closest(d == 0, count, s->ds, fc, ws_frame, stage, d, geo); // after the bins: only on their overflow
                 if ((rc = end()) != RTAMD_OK) return rc;
                 if (two_streams && d >= 2) HIP_TRY(hipStreamWaitEvent(geo, shaded(d - 2), 0));

@@ -11,7 +11,8 @@ namespace rtamd {
 
 // `depth` = recursion depth of the stage: selects the ray queue (depth % 3) and the hit list (depth & 1).
 // Screen binning of the primary rays of one pass (ws.bin_entries must be set): count, claim, fill, test.
-void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, hipStream_t stream);
+void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, bool cleared,
+                         hipStream_t stream);
 void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth,
                          hipStream_t stream);
 void launch_compact(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, bool spawn,

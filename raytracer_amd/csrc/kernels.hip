@@ -1214,10 +1214,11 @@ int walk_grid(long long groups) {
 }
 } // namespace
 
-void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, hipStream_t stream) {
+void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, bool cleared,
+                         hipStream_t stream) {
     const int total_static = fc.tiles_x * fc.tiles_y * 64;
-    (void)hipMemsetAsync(ws.bin_count, 0, sizeof(int32_t) * (size_t)ws.num_bins, stream);
-    (void)hipMemsetAsync(ws.bin_state, 0, sizeof(BinState), stream);
+    // bin_state (256 bytes) and bin_count are neighbours; the caller clears them with the frame's counters for the first pass
+    if (!cleared) (void)hipMemsetAsync(ws.bin_state, 0, 256 + sizeof(int32_t) * (size_t)ws.num_bins, stream);
     // Small faces (less than ten pixels of the whole image each, on average) share their atomics wave by wave.  Not
     // in a partitioned frame: a rank bins only the rows it owns, the atomics are few, and the shared loop only costs
     // (one rank of eight at 4K: 0.188 vs 0.201 ms).

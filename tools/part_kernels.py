@@ -1,0 +1,19 @@
+"""One rank's share of a frame, one frame at a time on one stream, for a kernel trace:
+    rocprofv3 --kernel-trace --stats --output-format csv -d OUT -- python3 tools/part_kernels.py WORKLOAD WORLD"""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from raytracer_amd import _lib as L  # noqa: E402
+from raytracer_amd import tiles, workloads  # noqa: E402
+
+name, world = sys.argv[1], int(sys.argv[2])
+w = workloads.get(name)
+fly, params, cam = workloads.make_flyscene(w)
+p = tiles.part_params(fly.params_copy(row_tile=16), world, 0)
+p.flags = L.FLAG_SINGLE_STREAM
+rgb = torch.zeros((fly.local_rows(p), w["width"], 3), dtype=torch.float32, device="cuda")
+for _ in range(50):
+    fly.render_device(rgb, params=p, camera=cam)
+torch.cuda.synchronize()
