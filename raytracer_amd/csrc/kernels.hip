@@ -719,6 +719,11 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(DeviceScene sc, FrameCons
     }
 }
 
+// Candidates per round trip in raster_kernel.  Two: 70 VGPRs and seven waves per SIMD; four take 84 and five waves,
+// which costs more than the longer chains of dependent loads (bunny at 4K 6 %, 1.1 M-face field 3 %).
+#ifndef RT_RASTER_BATCH
+#define RT_RASTER_BATCH 2
+#endif
 template <bool COUNT>
 __global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int total_static) {
     if (!bins_accepted(ws)) return;
@@ -740,13 +745,13 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst 
             const int bin = by * fc.bins_x + bx;
             const int begin = ws.bin_start[bin], nlist = ws.bin_count[bin], nbig = ws.bin_state->num_big;
             if (COUNT) ++w_box;
-            // Candidates are taken four at a time: the four index loads, then the four plane loads, are independent,
-            // so a long list costs a quarter of the dependent-load round trips.  The order of the candidates does
+            // Candidates are taken a few at a time (RT_RASTER_BATCH): their index loads, then their plane loads, are
+            // independent, so a long list costs that much fewer dependent-load round trips.  The order of the candidates does
             // not matter: equal distances are settled by the faces' ranks.
-            for (int e = 0; e < nlist + nbig; e += 4) {
-                int idx[4];
+            for (int e = 0; e < nlist + nbig; e += RT_RASTER_BATCH) {
+                int idx[RT_RASTER_BATCH];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < RT_RASTER_BATCH; ++k) {
                     const int ek = e + k;
                     int i = -1;
                     if (ek < nlist) {
@@ -757,14 +762,14 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst 
                     }
                     idx[k] = i;
                 }
-                // The planes of the four up front, the vertices only of a face whose plane the ray meets in range.  (Whole
+                // The planes of the batch up front, the vertices only of a face whose plane the ray meets in range.  (Whole
                 // records up front save that second round trip and make a lone frame's raster pass 5 % shorter, but
                 // with frames in flight the fetches they waste cost 1-7 % of the throughput.)
-                float4 pn[4];
+                float4 pn[RT_RASTER_BATCH];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) pn[k] = sc.tris[(size_t)max(idx[k], 0) * 4];
+                for (int k = 0; k < RT_RASTER_BATCH; ++k) pn[k] = sc.tris[(size_t)max(idx[k], 0) * 4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < RT_RASTER_BATCH; ++k) {
                     const int i = idx[k];
                     if (i < 0) continue;
                     // exact plane + three-edge test, src/flyscene.cpp:752-789
@@ -803,6 +808,11 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst 
 // faces' farthest extent along the direction: the scan ends at the first face that lies wholly behind the
 // ray's origin, or at the first face that blocks the sample.
 // ---------------------------------------------------------------------------------------------
+// Candidates per round trip in shadow_grid_kernel.  Three: 70 VGPRs, seven waves per SIMD (four: 80 and six, 1-3 %
+// slower; two: eight waves, but the chains get too long; six: four waves, 8-25 % slower).
+#ifndef RT_SHADOW_BATCH
+#define RT_SHADOW_BATCH 3
+#endif
 template <bool COUNT>
 __global__ __launch_bounds__(64) void shadow_grid_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth) {
     const int lane = (int)threadIdx.x;
@@ -844,17 +854,17 @@ __global__ __launch_bounds__(64) void shadow_grid_kernel(DeviceScene sc, FrameCo
             if (fx >= 0.0f && fy >= 0.0f && fx < (float)res && fy < (float)res) {
                 const int cell = first_cell + (int)fy * res + (int)fx;
                 const int begin = sc.grid_cells[cell], end = sc.grid_cells[cell + 1];
-                // four candidates at a time: independent entry loads, then independent plane loads
-                for (int e = begin + 4 * sub; e < end && !blocked; e += 4 * split) {
-                    int2 ent[4];
+                // a few candidates at a time (RT_SHADOW_BATCH): independent entry loads, then independent plane loads
+                for (int e = begin + RT_SHADOW_BATCH * sub; e < end && !blocked; e += RT_SHADOW_BATCH * split) {
+                    int2 ent[RT_SHADOW_BATCH];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) ent[k] = sc.grid_entries[min(e + k, end - 1)];
-                    float4 pn[4];
+                    for (int k = 0; k < RT_SHADOW_BATCH; ++k) ent[k] = sc.grid_entries[min(e + k, end - 1)];
+                    float4 pn[RT_SHADOW_BATCH];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) pn[k] = sc.tris[ent[k].x * 4 + 0];
+                    for (int k = 0; k < RT_SHADOW_BATCH; ++k) pn[k] = sc.tris[ent[k].x * 4 + 0];
                     bool behind = false;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
+                    for (int k = 0; k < RT_SHADOW_BATCH; ++k) {
                         if (blocked || behind || e + k >= end) continue;
                         if (__int_as_float(ent[k].y) < z) { // this face and all later ones lie behind the origin
                             behind = true;
