@@ -666,6 +666,8 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     fs.binned = bins_ok;
     ws_frame.bin_max_list = s->bin_always ? 0x7fffffff : kMaxAverageBinList;
     ws_frame.num_bins = bins_x * bins_y;
+    static const int forced_waves = getenv("RTAMD_FULL_WAVES") ? atoi(getenv("RTAMD_FULL_WAVES")) : -1; // experiment hook
+    ws_frame.full_waves = forced_waves >= 0 ? forced_waves : s->num_slots > 1; // several caller streams: frames overlap
 
     const bool count = (p->flags & RTAMD_FLAG_COUNT_WORK) != 0;
     const bool timed = (p->flags & RTAMD_FLAG_TIME_KERNELS) != 0;

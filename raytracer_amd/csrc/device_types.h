@@ -117,6 +117,10 @@ struct Workspace {
     // host memory the pass reports its BinState to (total, nonempty, fallback, 1), so that the host can leave the
     // binning out of the NEXT frames of a view whose lists are too long; never read by the device
     int32_t *bin_feedback;
+    // Frames overlap on the GPU (the scene is rendered on several streams): small bounce launches keep full waves of
+    // one ray per lane, which is the least work, instead of spreading the rays over more, narrower waves, which is
+    // the shortest chain for a launch alone on the chip.  Same results either way.
+    int32_t full_waves;
 };
 
 } // namespace rtamd
