@@ -17,6 +17,9 @@ export GPU_MAX_HW_QUEUES=16
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -- \
   python3 "$ROOT/bench.py" --cpu-seconds 0 > "$OUT/bench_under_rocprof_default.json" 2> "$OUT/trace_default.log" || exit 1
 # 3. ... and with every kernel alone on the GPU: these averages are the ones the roofline's avg_launch_ms must match
+# (RTAMD_FULL_WAVES=1: the kernels in the form the default command runs them; a scene rendered on one stream only
+# would spread its bounce rays over narrower waves)
+export RTAMD_FULL_WAVES=1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_serial" -- \
   python3 "$ROOT/bench.py" --cpu-seconds 0 --in-flight 1 --single-stream > "$OUT/bench_under_rocprof_serial.json" 2> "$OUT/trace_serial.log" || exit 1
 cd "$ROOT"
