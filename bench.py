@@ -69,8 +69,9 @@ def parse():
     ap.add_argument("--row-tile", type=int, default=16)
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH: faces per leaf (0 = library default)")
     ap.add_argument("--sah-bins", type=int, default=0, help="BVH: SAH bins (0 = library default)")
-    ap.add_argument("--in-flight", type=int, default=8,
-                    help="frames enqueued at a time, each on a stream of its own (1..8)")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="frames enqueued at a time, each on a stream of its own (1..16; default: 16 on one GPU, 8 per rank with "
+                         "several, where more do not help; fewer when the frames' workspaces would take more than 64 GB)")
     ap.add_argument("--hw-queues", type=int, default=16,
                     help="hardware queues asked of the HIP runtime (GPU_MAX_HW_QUEUES; 0 = leave the environment alone, and then "
                          "at most 4 frames in flight on one GPU, 2 with several)")
@@ -200,7 +201,10 @@ def main():
     # below the number of hardware queues, or the waits stall for good.
     queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
     piped = world > 1 or a.force_pipeline
-    in_flight = max(1, min(a.in_flight, 8, max(1, queues - 2) if piped else max(4, queues)))
+    # a frame's workspace: 44 four-byte planes per ray slot and two bytes per shadow ray of a slot
+    slot_bytes = (W * ((H + world - 1) // world)) * (176 + 2 * len(w["lights"]) * (1 + w["soft_points"]))
+    in_flight = max(1, min(a.in_flight or (8 if piped else 16), 16, max(1, queues - 2) if piped else max(4, queues),
+                           max(2, int(64e9 // max(slot_bytes, 1)))))
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(in_flight - 1)]
     turn = [0]
     if not piped:
@@ -255,6 +259,11 @@ def main():
 
     timed = tiles.part_params(base, world, rank)
     timed.flags = L.FLAG_SINGLE_STREAM if a.single_stream else 0
+    # set-up, not warm-up: the scene allocates a stream's workspace at the first frame it sees on that stream
+    # (hipMalloc, a device-wide wait), so every stream renders once before the warm-up steps begin
+    for _ in range(in_flight):
+        frame(timed)
+    sync()
     for _ in range(a.warmup):
         frame(timed)
     sync()

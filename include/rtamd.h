@@ -228,8 +228,8 @@ int rtamd_render(rtamd_scene *scene, const rtamd_camera *cam, const rtamd_render
  * synchronisation; outputs are DEVICE pointers on the scene's device (face_id, t_hit may be NULL;
  * t_hit = local_rows*width floats, primary hit distance, 0 on a miss).  rtamd_render_stats()
  * waits for the frames enqueued so far and returns the counters of the most recent call.
- * Frames in flight: the scene keeps one workspace per stream it is rendered on (eight at most;
- * a ninth stream takes over the least recently used one, after the host has waited for its last
+ * Frames in flight: the scene keeps one workspace per stream it is rendered on (sixteen at most;
+ * a seventeenth stream takes over the least recently used one, after the host has waited for its last
  * frame), so frames enqueued on different streams may run at the same time -- the deeper, latency-
  * bound stages of one frame then fill the gaps of the other.  Streams overlap only while each has a
  * hardware queue of its own: the HIP runtime gives a process four unless GPU_MAX_HW_QUEUES says

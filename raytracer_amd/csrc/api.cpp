@@ -62,7 +62,7 @@ struct TimedLaunch {
     int kind; // 0 closest-hit walk, 1 shadow walk, 2 compaction, 3 shading, 4 other, 5 whole frame, 6 screen-bin pass
 };
 
-constexpr int kMaxFrameSlots = 8;
+constexpr int kMaxFrameSlots = 16;
 
 // What one frame in flight owns.
 struct FrameSlot {

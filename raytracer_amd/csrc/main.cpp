@@ -8,7 +8,7 @@
 //
 // --frames N renders N more views of a slow orbit straight into device buffers, F of them enqueued at a time, each
 // on a HIP stream of its own (rtamd_render_device keeps one workspace per stream): the way a host that renders a
-// sequence gets the frames to overlap on the GPU (F up to 8; above 4 the program asks the HIP runtime for eight
+// sequence gets the frames to overlap on the GPU (F up to 16; above 4 the program asks the HIP runtime for sixteen
 // hardware queues, unless GPU_MAX_HW_QUEUES is already set).
 #include <hip/hip_runtime.h>
 
@@ -52,7 +52,7 @@ int main(int argc, char **argv) {
         } else if (a == "--frames") {
             frames = std::atoi(next());
         } else if (a == "--in-flight") {
-            in_flight = std::min(std::max(std::atoi(next()), 1), 8);
+            in_flight = std::min(std::max(std::atoi(next()), 1), 16);
         } else if (a == "--device-builder") {
             fly.build.builder = RTAMD_BUILDER_DEVICE_LBVH;
         } else if (a == "--move") {
@@ -65,7 +65,7 @@ int main(int argc, char **argv) {
     }
     // Frames on different streams overlap only while each stream has a hardware queue of its own; the HIP runtime
     // gives a process four unless told otherwise before its first call.
-    if (frames > 0 && in_flight > 4) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    if (frames > 0 && in_flight > 4) setenv("GPU_MAX_HW_QUEUES", "16", 0);
     using clk = std::chrono::steady_clock;
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     std::printf("Initializing scene ...\n");

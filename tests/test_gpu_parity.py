@@ -220,9 +220,9 @@ def test_frames_in_flight_on_several_streams():
 
     fly, _ = make_pair("reflect_test", width=160, height=120)
     cams = []
-    for k in range(10):
-        fly.camera_translate(0.24, -0.12, 0.6)
-        fly.camera_rotate(0.05, -0.03)
+    for k in range(18):
+        fly.camera_translate(0.13, -0.07, 0.33)
+        fly.camera_rotate(0.028, -0.017)
         cams.append(fly.getCamera())
     shape = (120, 160)
     want = []
@@ -233,8 +233,8 @@ def test_frames_in_flight_on_several_streams():
         torch.cuda.synchronize()
         want.append((rgb.cpu().numpy(), fid.cpu().numpy()))
     assert fly.stats().rays_bounce > 0
-    assert not np.array_equal(want[0][1], want[9][1])
-    for nstreams in (2, 3, 10):  # 10 > the eight workspaces a scene keeps: the least recently used one changes hands
+    assert not np.array_equal(want[0][1], want[17][1])
+    for nstreams in (2, 3, 18):  # 18 > the sixteen workspaces a scene keeps: the least recently used one changes hands
         streams = [torch.cuda.Stream() for _ in range(nstreams)]
         outs = [(torch.zeros(shape + (3,), dtype=torch.float32, device="cuda"), torch.zeros(shape, dtype=torch.int32, device="cuda"))
                 for _ in cams]

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for wl in bunny_1080p bunny_1000 field_4k; do
   timeout -k 10 300 python3 "$ROOT/bench.py" --workload $wl $([ $wl = bunny_1080p ] || echo --cpu-seconds 0) 2>/dev/null | tail -1 > "$OUT/bench_$wl.json" || exit 1
 done
-# 2. kernel trace of the default command (eight frames in flight: kernels of different frames overlap) ...
+# 2. kernel trace of the default command (sixteen frames in flight: kernels of different frames overlap) ...
 # (the profiler starts the HIP runtime before bench.py can ask for its hardware queues, so the shell does)
 export GPU_MAX_HW_QUEUES=16
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -- \
