@@ -533,7 +533,16 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
 struct PixelBox {
     int x0, y0, x1, y1; // bins, inclusive, clamped to the image
     bool empty, big;
+    // The projected triangle, for faces whose box spans several bins: a bin none of whose pixels can lie inside it
+    // (face_touches_bin) is left out.  Edge k runs from (ex[k], ey[k]) along (dx[k], dy[k]), oriented so that the
+    // inside is on its left; coordinates are pixel indices (the sample offset of the pass is taken off).
+    bool cull;
+    float ex[3], ey[3], dx[3], dy[3];
 };
+
+// Widening of the projected box and triangle, in pixels: covers the rounding of the projection (about 1e-3 pixel at
+// 8K) and of the exact test many times over.
+constexpr float kBinMargin = 0.25f;
 
 // pixel position of a world point: inverse of camera_direction.  false: the point is not in front of the eye.
 __device__ __forceinline__ bool project_point(const FrameConst &fc, V3 p, float &px, float &py) {
@@ -554,7 +563,7 @@ __device__ __forceinline__ bool project_point(const FrameConst &fc, V3 p, float 
 
 __device__ __forceinline__ PixelBox face_bins(const DeviceScene &sc, const FrameConst &fc, int tri) {
     PixelBox b;
-    b.empty = false, b.big = false;
+    b.empty = false, b.big = false, b.cull = false;
     const float4 p0 = sc.tris[tri * 4 + 1], p1 = sc.tris[tri * 4 + 2], p2 = sc.tris[tri * 4 + 3];
     float x0 = 0, y0 = 0, x1 = 0, y1 = 0, x2 = 0, y2 = 0;
     const bool ok0 = project_point(fc, mk(p0.x, p0.y, p0.z), x0, y0);
@@ -565,7 +574,7 @@ __device__ __forceinline__ PixelBox face_bins(const DeviceScene &sc, const Frame
     if (ok) {
         // pixel (x, y) samples at (x + sub_x, y + sub_y): shift the box instead of the samples; the margin covers
         // the rounding of the projection (about 1e-3 pixel at 8K) and of the exact test many times over
-        const float margin = 0.25f;
+        const float margin = kBinMargin;
         xlo = fminf(fminf(x0, x1), x2) - margin - fc.sub_x, xhi = fmaxf(fmaxf(x0, x1), x2) + margin - fc.sub_x;
         ylo = fminf(fminf(y0, y1), y2) - margin - fc.sub_y, yhi = fmaxf(fmaxf(y0, y1), y2) + margin - fc.sub_y;
     } else {
@@ -581,7 +590,45 @@ __device__ __forceinline__ PixelBox face_bins(const DeviceScene &sc, const Frame
     }
     b.x0 = (int)fx0 / kBinPixels, b.x1 = (int)fx1 / kBinPixels, b.y0 = (int)fy0 / kBinPixels, b.y1 = (int)fy1 / kBinPixels;
     if ((b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1) > kBigBins) b.big = true;
+    // The box of a triangle holds about twice the bins the triangle touches.  Worth three edge evaluations per bin
+    // once the box spans 2 x 2 bins; only with all vertices near the screen (the edge functions are products of pixel
+    // coordinates: their rounding must stay far below the margin term) and a triangle that has an inside.
+    b.cull = false;
+    if (ok && !b.big && b.x1 > b.x0 && b.y1 > b.y0) {
+        const float lim = 16384.0f;
+        const float area = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0);
+        const bool near_screen = fabsf(x0) < lim && fabsf(y0) < lim && fabsf(x1) < lim && fabsf(y1) < lim && fabsf(x2) < lim && fabsf(y2) < lim;
+        if (near_screen && fabsf(area) > 1e-3f) {
+            b.cull = true;
+            const float px[3] = {x0 - fc.sub_x, x1 - fc.sub_x, x2 - fc.sub_x}, py[3] = {y0 - fc.sub_y, y1 - fc.sub_y, y2 - fc.sub_y};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int n = k == 2 ? 0 : k + 1;
+                // counter-clockwise (area > 0): inside is left of p_k -> p_n; clockwise: left of p_n -> p_k
+                const int from = area > 0.0f ? k : n, to = area > 0.0f ? n : k;
+                b.ex[k] = px[from], b.ey[k] = py[from];
+                b.dx[k] = px[to] - px[from], b.dy[k] = py[to] - py[from];
+            }
+        }
+    }
     return b;
+}
+
+// Can a pixel of bin (x, y) lie inside the projected triangle widened by kBinMargin?  E(r) = dx (r.y - ey) - dy (r.x - ex)
+// is >= 0 left of an edge; moving r by up to the margin in x and y changes E by at most margin (|dx| + |dy|), so a bin
+// whose most favourable corner stays below minus that lies outside for good.
+__device__ __forceinline__ bool face_touches_bin(const PixelBox &b, int x, int y) {
+    if (!b.cull) return true;
+    const float rx0 = (float)(x * kBinPixels), ry0 = (float)(y * kBinPixels);
+    const float rx1 = rx0 + (float)(kBinPixels - 1), ry1 = ry0 + (float)(kBinPixels - 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float cy = b.dx[k] >= 0.0f ? ry1 : ry0; // E grows with r.y when dx > 0 ...
+        const float cx = b.dy[k] >= 0.0f ? rx0 : rx1; // ... and falls with r.x when dy > 0
+        const float e = b.dx[k] * (cy - b.ey[k]) - b.dy[k] * (cx - b.ex[k]);
+        if (e < -kBinMargin * (fabsf(b.dx[k]) + fabsf(b.dy[k]))) return false;
+    }
+    return true;
 }
 
 // does this rank render any row of bin row `by`?  (row tiles are dealt round-robin, see global_row)
@@ -622,7 +669,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(DeviceScene sc, FrameCon
     const int tri = (int)(blockIdx.x * 256 + threadIdx.x);
     if (AGG) {
     PixelBox b;
-    b.empty = true, b.big = false, b.x0 = b.y0 = 0, b.x1 = b.y1 = -1;
+    b.empty = true, b.big = false, b.cull = false, b.x0 = b.y0 = 0, b.x1 = b.y1 = -1;
     if (tri < num_tris) b = face_bins(sc, fc, tri);
     if (!b.empty && b.big) {
         const int at = atomicAdd(&ws.bin_state->num_big, 1);
@@ -632,7 +679,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(DeviceScene sc, FrameCon
     for (int j = 0; __ballot(j < count) != 0; ++j) { // the wave steps through its faces' bins together
         const bool active = j < count;
         const int y = b.y0 + (active ? j / w : 0), x = b.x0 + (active ? j % w : 0);
-        const bool owned = active && bin_row_owned(fc, y);
+        const bool owned = active && bin_row_owned(fc, y) && face_touches_bin(b, x, y);
         (void)shared_increment(ws.bin_count, y * fc.bins_x + x, owned);
     }
     return;
@@ -647,7 +694,8 @@ __global__ __launch_bounds__(256) void bin_count_kernel(DeviceScene sc, FrameCon
     }
     for (int y = b.y0; y <= b.y1; ++y) {
         if (!bin_row_owned(fc, y)) continue;
-        for (int x = b.x0; x <= b.x1; ++x) atomicAdd(&ws.bin_count[y * fc.bins_x + x], 1);
+        for (int x = b.x0; x <= b.x1; ++x)
+            if (face_touches_bin(b, x, y)) atomicAdd(&ws.bin_count[y * fc.bins_x + x], 1);
     }
 }
 
@@ -698,13 +746,13 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(DeviceScene sc, FrameCons
     if (!bins_accepted(ws)) return;
     if (AGG) {
     PixelBox b;
-    b.empty = true, b.big = false, b.x0 = b.y0 = 0, b.x1 = b.y1 = -1;
+    b.empty = true, b.big = false, b.cull = false, b.x0 = b.y0 = 0, b.x1 = b.y1 = -1;
     if (tri < num_tris) b = face_bins(sc, fc, tri);
     const int w = b.x1 - b.x0 + 1, count = (b.empty || b.big) ? 0 : w * (b.y1 - b.y0 + 1);
     for (int j = 0; __ballot(j < count) != 0; ++j) {
         const bool active = j < count;
         const int y = b.y0 + (active ? j / w : 0), x = b.x0 + (active ? j % w : 0);
-        const bool owned = active && bin_row_owned(fc, y);
+        const bool owned = active && bin_row_owned(fc, y) && face_touches_bin(b, x, y);
         const int bin = y * fc.bins_x + x;
         const int at = shared_increment(ws.bin_count, bin, owned);
         if (owned) ws.bin_entries[ws.bin_start[bin] + at] = tri;
@@ -717,6 +765,7 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(DeviceScene sc, FrameCons
     for (int y = b.y0; y <= b.y1; ++y) {
         if (!bin_row_owned(fc, y)) continue;
         for (int x = b.x0; x <= b.x1; ++x) {
+            if (!face_touches_bin(b, x, y)) continue;
             const int bin = y * fc.bins_x + x;
             ws.bin_entries[ws.bin_start[bin] + atomicAdd(&ws.bin_count[bin], 1)] = tri;
         }
