@@ -72,30 +72,49 @@ __device__ __forceinline__ int cell_of(float x, float origin, const GridFrame &g
     return (int)fminf(fmaxf(f, 0.0f), (float)(g.res - 1));
 }
 
-__global__ void count_kernel(int n, GridFrame g, const float *ulo, const float *uhi, const float *vlo, const float *vhi, unsigned *counts) {
+// the cells of its box a face is entered into (shadow_grid.hpp: cell_touched)
+struct CullFrame {
+    Basis bs;
+    double margin, cell, slack;
+};
+
+__global__ void count_kernel(const TriRecord *tris, int n, GridFrame g, CullFrame cf, const float *ulo, const float *uhi, const float *vlo,
+                             const float *vhi, unsigned *counts) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n) return;
     const int x0 = cell_of(ulo[i], g.u0, g), x1 = cell_of(uhi[i], g.u0, g), y0 = cell_of(vlo[i], g.v0, g), y1 = cell_of(vhi[i], g.v0, g);
-    counts[i] = (unsigned)(x1 - x0 + 1) * (unsigned)(y1 - y0 + 1);
+    const CellCull cull = make_cell_cull(tris[i].v0, tris[i].v1, tris[i].v2, cf.bs.U, cf.bs.V, (int64_t)x1 - x0 + 1, (int64_t)y1 - y0 + 1, cf.margin);
+    if (!cull.on) {
+        counts[i] = (unsigned)(x1 - x0 + 1) * (unsigned)(y1 - y0 + 1);
+        return;
+    }
+    unsigned c = 0;
+    for (int y = y0; y <= y1; ++y)
+        for (int x = x0; x <= x1; ++x) c += cell_touched(cull, x, y, (double)g.u0, (double)g.v0, cf.cell, cf.slack) ? 1u : 0u;
+    counts[i] = c;
 }
 
 constexpr unsigned kWideFace = 2048; // cells; a face touching more is emitted by a whole workgroup (a ground plane touches millions)
 
-__global__ void emit_kernel(int n, GridFrame g, const float *ulo, const float *uhi, const float *vlo, const float *vhi, const float *zmax,
-                            const unsigned *counts, const unsigned *offsets, unsigned long long *keys, int *vals) {
+__global__ void emit_kernel(const TriRecord *tris, int n, GridFrame g, CullFrame cf, const float *ulo, const float *uhi, const float *vlo,
+                            const float *vhi, const float *zmax, const unsigned *counts, const unsigned *offsets, unsigned long long *keys, int *vals) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= n || counts[i] > kWideFace) return;
     const int x0 = cell_of(ulo[i], g.u0, g), x1 = cell_of(uhi[i], g.u0, g), y0 = cell_of(vlo[i], g.v0, g), y1 = cell_of(vhi[i], g.v0, g);
+    const CellCull cull = make_cell_cull(tris[i].v0, tris[i].v1, tris[i].v2, cf.bs.U, cf.bs.V, (int64_t)x1 - x0 + 1, (int64_t)y1 - y0 + 1, cf.margin);
     const unsigned long long far_first = (unsigned long long)(~orderable(zmax[i])); // descending extent = ascending key
     size_t at = offsets[i];
     for (int y = y0; y <= y1; ++y)
-        for (int x = x0; x <= x1; ++x, ++at) {
+        for (int x = x0; x <= x1; ++x) {
+            if (!cell_touched(cull, x, y, (double)g.u0, (double)g.v0, cf.cell, cf.slack)) continue;
             keys[at] = ((unsigned long long)((unsigned)y * (unsigned)g.res + (unsigned)x) << 32) | far_first;
             vals[at] = i;
+            ++at;
         }
 }
 
-// one workgroup per wide face
+// one workgroup per wide face (more than kWideFace = kCullMaxCells cells: its whole box is entered)
+static_assert(kWideFace == kCullMaxCells, "a face wide enough for emit_wide_kernel must be one the cell test leaves alone");
 __global__ void emit_wide_kernel(const int *wide, GridFrame g, const float *ulo, const float *uhi, const float *vlo, const float *vhi, const float *zmax,
                                  const unsigned *offsets, unsigned long long *keys, int *vals) {
     const int i = wide[blockIdx.x];
@@ -255,12 +274,15 @@ bool build_shadow_grids_device(const std::vector<TriRecord> &tris, const void *d
         int res = (int)std::lround(std::sqrt(density * (double)n));
         res = std::min(std::max(res, 16), 4096);
         GridFrame g;
+        CullFrame cf;
+        cf.bs = bs, cf.margin = margin;
         long long total = 0;
         std::vector<unsigned> host_counts(N);
         for (;; res /= 2) { // halve the resolution until the lists fit
             g.inv_cell = (float)((double)res / (extent * (1.0 + 1e-6)));
             g.u0 = (float)gu0, g.v0 = (float)gv0, g.res = res;
-            count_kernel<<<blocks, 256>>>(n, g, ulo, uhi, vlo, vhi, counts);
+            cf.cell = 1.0 / (double)g.inv_cell, cf.slack = cell_slack(margin, cf.cell);
+            count_kernel<<<blocks, 256>>>((const TriRecord *)d_tris, n, g, cf, ulo, uhi, vlo, vhi, counts);
             GRID_TRY(hipMemcpy(host_counts.data(), counts, N * sizeof(unsigned), hipMemcpyDeviceToHost));
             total = 0;
             for (unsigned c : host_counts) total += c;
@@ -288,7 +310,7 @@ bool build_shadow_grids_device(const std::vector<TriRecord> &tris, const void *d
             return false;
         }
         ms_alloc += now() - tp, tp = now();
-        emit_kernel<<<blocks, 256>>>(n, g, ulo, uhi, vlo, vhi, zmax, counts, offsets, keys, vals);
+        emit_kernel<<<blocks, 256>>>((const TriRecord *)d_tris, n, g, cf, ulo, uhi, vlo, vhi, zmax, counts, offsets, keys, vals);
         std::vector<int> wide;
         for (int i = 0; i < n; ++i)
             if (host_counts[(size_t)i] > kWideFace) wide.push_back(i);

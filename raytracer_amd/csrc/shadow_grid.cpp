@@ -121,6 +121,11 @@ void build_one(const FlatBvh &bvh, const float *dir, double scale, OneGrid &g, i
             return (int)std::min(std::max(f, 0.0f), (float)(res - 1));
         };
         const size_t ncells = (size_t)res * res;
+        const double cell_size = 1.0 / (double)inv_cell, slack = cell_slack(margin, cell_size);
+        auto cull_of = [&](size_t i, int x0, int x1, int y0, int y1) {
+            const TriRecord &t = bvh.tris[i];
+            return make_cell_cull(t.v0, t.v1, t.v2, Uf, Vf, (int64_t)x1 - x0 + 1, (int64_t)y1 - y0 + 1, margin);
+        };
         std::vector<std::atomic<int32_t>> count(ncells);
         for (std::atomic<int32_t> &c : count) c.store(0, std::memory_order_relaxed);
         std::atomic<int64_t> total{0};
@@ -128,11 +133,18 @@ void build_one(const FlatBvh &bvh, const float *dir, double scale, OneGrid &g, i
             int64_t mine = 0;
             for (size_t i = first; i < last && total.load(std::memory_order_relaxed) <= kMaxEntriesPerGrid; ++i) {
                 const int x0 = cell(box[i].ulo, u0), x1 = cell(box[i].uhi, u0), y0 = cell(box[i].vlo, v0), y1 = cell(box[i].vhi, v0);
-                const int64_t add = (int64_t)(x1 - x0 + 1) * (y1 - y0 + 1);
-                mine += add;
-                if (mine > kMaxEntriesPerGrid) break;
+                if ((int64_t)(x1 - x0 + 1) * (y1 - y0 + 1) > kMaxEntriesPerGrid) {
+                    mine = kMaxEntriesPerGrid + 1;
+                    break;
+                }
+                const CellCull cull = cull_of(i, x0, x1, y0, y1);
                 for (int y = y0; y <= y1; ++y)
-                    for (int x = x0; x <= x1; ++x) count[(size_t)y * res + x].fetch_add(1, std::memory_order_relaxed);
+                    for (int x = x0; x <= x1; ++x)
+                        if (cell_touched(cull, x, y, (double)u0, (double)v0, cell_size, slack)) {
+                            count[(size_t)y * res + x].fetch_add(1, std::memory_order_relaxed);
+                            ++mine;
+                        }
+                if (mine > kMaxEntriesPerGrid) break;
             }
             total.fetch_add(mine);
         });
@@ -152,9 +164,11 @@ void build_one(const FlatBvh &bvh, const float *dir, double scale, OneGrid &g, i
         parallel_ranges(n, threads, [&](size_t first, size_t last) {
             for (size_t i = first; i < last; ++i) {
                 const int x0 = cell(box[i].ulo, u0), x1 = cell(box[i].uhi, u0), y0 = cell(box[i].vlo, v0), y1 = cell(box[i].vhi, v0);
+                const CellCull cull = cull_of(i, x0, x1, y0, y1);
                 for (int y = y0; y <= y1; ++y)
                     for (int x = x0; x <= x1; ++x)
-                        g.entries[(size_t)count[(size_t)y * res + x].fetch_add(1, std::memory_order_relaxed)] = ShadowGridEntry{(int32_t)i, box[i].zmax};
+                        if (cell_touched(cull, x, y, (double)u0, (double)v0, cell_size, slack))
+                            g.entries[(size_t)count[(size_t)y * res + x].fetch_add(1, std::memory_order_relaxed)] = ShadowGridEntry{(int32_t)i, box[i].zmax};
             }
         });
         parallel_ranges(ncells, threads, [&](size_t first, size_t last) {
