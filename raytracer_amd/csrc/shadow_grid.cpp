@@ -106,8 +106,8 @@ void build_one(const FlatBvh &bvh, const float *dir, double scale, OneGrid &g, i
     if (n == 0) gu0 = gv0 = 0.0, gu1 = gv1 = 1.0;
     const double extent = std::max(std::max(gu1 - gu0, gv1 - gv0), 1e-30);
     // Cells per face.  The kernel is bound by fetching the lists, and finer cells mean shorter lists (fewer faces
-    // whose box merely touches the cell): 4 cells per face against 2 take 6-10 % off the shadow rays for 1.7x the
-    // entries; 8 gain little more and cost the build and the caches.
+    // that merely come near the cell): 4 cells per face against 2 take 6-10 % off the shadow rays for 1.7x the
+    // entries, 6 another 2-4 % for 1.3x; 8 and 12 gain little more and cost the build and the caches.
     const double density = shadow_grid_density();
     int res = (int)std::lround(std::sqrt(density * (double)std::max<size_t>(n, 1)));
     res = std::min(std::max(res, 16), 4096);
@@ -186,8 +186,8 @@ void build_one(const FlatBvh &bvh, const float *dir, double scale, OneGrid &g, i
 } // namespace
 
 double shadow_grid_density() {
-    static const double density = std::getenv("RTAMD_GRID_DENSITY") ? std::atof(std::getenv("RTAMD_GRID_DENSITY")) : 4.0;
-    return density > 0.0 ? density : 4.0;
+    static const double density = std::getenv("RTAMD_GRID_DENSITY") ? std::atof(std::getenv("RTAMD_GRID_DENSITY")) : 6.0;
+    return density > 0.0 ? density : 6.0;
 }
 
 void build_shadow_grids(const FlatBvh &bvh, const float *samples, int num_samples, ShadowGrids &out) {
