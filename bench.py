@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=None, help="default: bunny_1080p (1 GPU) / field_4k (several GPUs)")
+    ap.add_argument("--size", default=None, help="WxH: render the workload at another image size (experiments; the line names it)")
     ap.add_argument("--row-tile", type=int, default=16)
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH: faces per leaf (0 = library default)")
     ap.add_argument("--sah-bins", type=int, default=0, help="BVH: SAH bins (0 = library default)")
@@ -186,6 +187,10 @@ def main():
 
     name = a.workload or ("bunny_1080p" if world == 1 else "field_4k")
     w = workloads.get(name)
+    if a.size:
+        w = dict(w)
+        w["width"], w["height"] = (int(x) for x in a.size.lower().split("x"))
+        name = "%s@%s" % (name, a.size.lower())
     t0 = time.time()
     fly, params, cam = workloads.make_flyscene(w, max_leaf_faces=a.max_leaf, sah_bins=a.sah_bins, shadow_rays=a.shadow_rays, primary_rays=a.primary_rays, builder=a.builder)
     info = fly.info()
