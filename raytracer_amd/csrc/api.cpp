@@ -624,6 +624,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     // the tree walk's with the pixels.  Measured on a 1.1 M-face field: still ahead at one face per pixel (one
     // rank of eight at 4K), behind at 7.5 faces per pixel (a 256x144 image of 278 K faces).
     static const double faces_per_pixel_max = getenv("RTAMD_BIN_FACES_PER_PIXEL") ? atof(getenv("RTAMD_BIN_FACES_PER_PIXEL")) : 2.0;
+    bool bins_kept_before = false;
     bool bins_ok = s->bin_primary && fs.ws.bin_entries != nullptr && bins_x < 32768 && bins_y < 32768 &&
                    (s->bin_always || (double)s->info.num_device_faces <= faces_per_pixel_max * (double)pixels);
     if (bins_ok && fs.feedback && !s->bin_always) {
@@ -636,6 +637,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
         }
         const long long total = fs.feedback[0], nonempty = fs.feedback[1];
         const bool turned_down = fs.feedback[3] != 0 && (fs.feedback[2] != 0 || total > (long long)kMaxAverageBinList * std::max(nonempty, 1ll));
+        bins_kept_before = fs.feedback[3] != 0 && !turned_down;
         if (turned_down && fs.frames_without_bins < 63) { // try the bins again every 64th frame: the camera may have moved
             bins_ok = false;
             ++fs.frames_without_bins;
@@ -666,6 +668,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     fs.binned = bins_ok;
     ws_frame.bin_max_list = s->bin_always ? 0x7fffffff : kMaxAverageBinList;
     ws_frame.num_bins = bins_x * bins_y;
+    ws_frame.bins_expected = bins_ok && bins_kept_before;
     static const int forced_waves = getenv("RTAMD_FULL_WAVES") ? atoi(getenv("RTAMD_FULL_WAVES")) : -1; // experiment hook
     ws_frame.full_waves = forced_waves >= 0 ? forced_waves : s->num_slots > 1; // several caller streams: frames overlap
 

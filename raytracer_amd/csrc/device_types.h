@@ -121,6 +121,9 @@ struct Workspace {
     // one ray per lane, which is the least work, instead of spreading the rays over more, narrower waves, which is
     // the shortest chain for a launch alone on the chip.  Same results either way.
     int32_t full_waves;
+    // The binning pass of the previous frame of this view kept its bins: the tree walk behind the bins, which only
+    // runs when a pass turns them down, gets a small grid (it strides over the pixels), cheap to launch and to drain.
+    int32_t bins_expected;
 };
 
 } // namespace rtamd

@@ -1319,7 +1319,7 @@ void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const 
     // bounce queues are at most as long as the slot count: that is the worst case the grid covers
     // With screen binning in use the primary walk only runs when the pass turned its bins down (overflow, or
     // lists too long to pay): a moderate grid (the kernel strides over the groups) keeps the usual early exit cheap.
-    const int blocks = primary && ws.bin_entries ? 16384 : walk_grid(primary ? fc.tiles_x * fc.tiles_y : ws.capacity / 64);
+    const int blocks = primary && ws.bin_entries ? (ws.bins_expected ? 2048 : 16384) : walk_grid(primary ? fc.tiles_x * fc.tiles_y : ws.capacity / 64);
     if (primary) {
         if (count)
             walk_kernel<kPrimary, true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, total_static);
