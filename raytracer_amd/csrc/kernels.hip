@@ -706,21 +706,31 @@ __global__ __launch_bounds__(256) void bin_count_kernel(DeviceScene sc, FrameCon
 }
 
 // Claims a contiguous range of the entry buffer for every bin: prefix sum inside a workgroup, one atomic per
-// workgroup.  Leaves bin_count = 0 for the fill pass to count up again.
+// workgroup.  A workgroup takes 2048 bins, eight per thread: the atomics all name one address and serialise in L2
+// (2025 of them, one per 256 bins of a 4K image, took 24 us; 8K has four times the bins).  Leaves bin_count = 0
+// for the fill pass to count up again.
+constexpr int kOffsetItems = 8;
 __global__ __launch_bounds__(256) void bin_offsets_kernel(Workspace ws) {
     __shared__ int s_wave[4], s_full[4];
     __shared__ int s_base;
-    const int bin = (int)(blockIdx.x * 256 + threadIdx.x);
+    const int bin0 = (int)(blockIdx.x * 256 + threadIdx.x) * kOffsetItems;
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-    const int c = bin < ws.num_bins ? ws.bin_count[bin] : 0;
-    // inclusive scan over the wave
-    int incl = c;
+    int c[kOffsetItems];
+    int mine = 0, full = 0;
+#pragma unroll
+    for (int k = 0; k < kOffsetItems; ++k) {
+        c[k] = bin0 + k < ws.num_bins ? ws.bin_count[bin0 + k] : 0;
+        mine += c[k];
+        full += c[k] > 0 ? 1 : 0;
+    }
+    // inclusive scan of the threads' sums over the wave, and the wave's count of non-empty bins
+    int incl = mine;
     for (int d = 1; d < 64; d <<= 1) {
         const int up = __shfl_up(incl, d, 64);
         if (lane >= d) incl += up;
     }
+    for (int d = 32; d > 0; d >>= 1) full += __shfl_xor(full, d, 64);
     if (lane == 63) s_wave[wave] = incl;
-    const int full = __popcll(__ballot(c > 0));
     if (lane == 0) s_full[wave] = full;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -734,11 +744,15 @@ __global__ __launch_bounds__(256) void bin_offsets_kernel(Workspace ws) {
         s_base = base;
     }
     __syncthreads();
-    int start = s_base + incl - c;
+    int start = s_base + incl - mine;
     for (int w = 0; w < wave; ++w) start += s_wave[w];
-    if (bin < ws.num_bins) {
-        ws.bin_start[bin] = start;
-        ws.bin_count[bin] = 0;
+#pragma unroll
+    for (int k = 0; k < kOffsetItems; ++k) {
+        if (bin0 + k < ws.num_bins) {
+            ws.bin_start[bin0 + k] = start;
+            ws.bin_count[bin0 + k] = 0;
+        }
+        start += c[k];
     }
 }
 
@@ -1300,7 +1314,7 @@ void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc
         else
             bin_count_kernel<false><<<face_blocks, 256, 0, stream>>>(sc, fc, ws, num_tris);
     }
-    bin_offsets_kernel<<<(ws.num_bins + 255) / 256, 256, 0, stream>>>(ws);
+    bin_offsets_kernel<<<(ws.num_bins + 256 * kOffsetItems - 1) / (256 * kOffsetItems), 256, 0, stream>>>(ws);
     if (num_tris > 0) {
         if (aggregate)
             bin_fill_kernel<true><<<face_blocks, 256, 0, stream>>>(sc, fc, ws, num_tris);
