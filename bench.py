@@ -431,7 +431,7 @@ def main():
                     fly.render_device(full[i % in_flight], params=whole, camera=cam, stream=streams[i % in_flight])
                 torch.cuda.synchronize(dev)
 
-            whole_frames(a.warmup + 1)
+            whole_frames(max(a.warmup, in_flight) + 1)  # every stream's workspace grows to the whole frame first
             t0 = time.perf_counter()
             whole_frames(a.steps)
             one_ms = (time.perf_counter() - t0) / a.steps * 1e3
