@@ -181,8 +181,11 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    # --force-pipeline under torch.distributed.run with ONE process: the several-GPU code path with the real collective
+    # (a gather among one), RCCL's stream and the barriers included
+    use_dist = world > 1 or (a.force_pipeline and "RANK" in os.environ)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     name = a.workload or ("bunny_1080p" if world == 1 else "field_4k")
@@ -230,7 +233,7 @@ def main():
         # sends the floats instead.
         def make_pipeline(as_bytes):
             pipe = tiles.GatherPipeline(mine, W, 3, dev, dtype=torch.uint8 if as_bytes else torch.float32, depth=in_flight,
-                                        rehearse=world == 1)
+                                        rehearse=not use_dist, collective_alone=use_dist)
             bufs = [torch.zeros((max(rows, 1), W, 3), dtype=torch.float32, device=dev) for _ in range(in_flight)] if as_bytes else None
 
             def frame(p):
@@ -250,7 +253,7 @@ def main():
 
     def sync(flush_now=None):
         (flush_now or flush)()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -312,7 +315,7 @@ def main():
                          st.ms_raster, st.launches_raster], dtype=torch.float64, device=dev)
     wk = torch.tensor([work.box_tests[0], work.tri_plane[0], work.tri_edge[0], work.box_tests[1], work.tri_plane[1], work.tri_edge[1],
                        work.box_tests[2], work.tri_plane[2], work.tri_edge[2]], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(wk, op=dist.ReduceOp.SUM)
@@ -441,7 +444,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(w, cam, a.cpu_seconds)
             out["gpu_over_cpu"] = round(value / max(out["cpu_baseline"]["value"], 1e-9), 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

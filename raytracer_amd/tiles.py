@@ -127,21 +127,23 @@ class GatherPipeline:
     `rehearse` (one process only) puts a device copy on a side stream where the collective would be, with the same
     waits between the streams: the stream topology of a several-GPU run on one GPU."""
 
-    def __init__(self, params, width, channels, device, dtype=torch.float32, group=None, dst=0, depth=2, rehearse=False):
+    def __init__(self, params, width, channels, device, dtype=torch.float32, group=None, dst=0, depth=2, rehearse=False, collective_alone=False):
         self.params, self.group, self.dst = params, group, dst
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # collective_alone: a group of ONE process still goes through the collective (a test of the plumbing around it)
+        self.single = self.world == 1 and not (collective_alone and dist.is_initialized())
         self.depth = max(2, int(depth))
         rows, rows_max, index_padded, _, _ = layout(params, self.world)
         self.rows_max = max(rows_max, 1)
         shape = (self.rows_max, width, channels)
         self.send = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(self.depth)]
         self.recv = None
-        if self.world > 1 and self.rank == dst:
+        if not self.single and self.rank == dst:
             self.recv = [torch.empty((self.world,) + shape, dtype=dtype, device=device) for _ in range(self.depth)]
             self.index = index_padded.to(device)
         self.side = None
-        if self.world == 1 and rehearse:
+        if self.single and rehearse:
             self.side = torch.cuda.Stream(device)
             self.recv = [torch.empty(shape, dtype=dtype, device=device) for _ in range(self.depth)]
         self.work = [None] * self.depth
@@ -155,7 +157,7 @@ class GatherPipeline:
         if self.work[b] is not True:
             self.work[b].wait()  # a collective's handle or the rehearsal's event: the current stream waits, not the host
         self.work[b] = None
-        if self.world == 1:
+        if self.single:
             return (self.recv if self.side is not None else self.send)[b][: self.params.height].clone()
         if self.rank != self.dst:
             return None
@@ -174,7 +176,7 @@ class GatherPipeline:
     def submit(self, stream=None):
         b = self.turn
         with self._on(stream):  # the collective starts behind what this stream has enqueued
-            if self.world == 1:
+            if self.single:
                 self.work[b] = True
                 if self.side is not None:
                     self.side.wait_stream(torch.cuda.current_stream(self.send[b].device))
@@ -192,4 +194,4 @@ class GatherPipeline:
 
     def drain(self):
         out = [self._finish((self.turn + i) % self.depth) for i in range(self.depth)]
-        return [x for x in out if x is not None] if (self.world == 1 or self.rank == self.dst) else []
+        return [x for x in out if x is not None] if (self.single or self.rank == self.dst) else []

@@ -28,12 +28,14 @@ W, H = 64, 48
 base = R.default_params(W, H, row_tile=8)
 mine = tiles.part_params(base, world, rank)
 rows = R._lib.lib().rtamd_local_rows(__import__("ctypes").byref(mine))
-streams = [torch.cuda.current_stream(dev), torch.cuda.Stream(dev)]
+F = int(os.environ.get("FRAMES_IN_FLIGHT", "2"))  # with more than 2, export GPU_MAX_HW_QUEUES=16 first
+streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(F - 1)]
+FRAMES = 3 * F
 for dtype in (torch.uint8, torch.float32):
-    pipe = tiles.GatherPipeline(mine, W, 3, dev, dtype=dtype)
+    pipe = tiles.GatherPipeline(mine, W, 3, dev, dtype=dtype, depth=F, collective_alone=True)  # one rank: RCCL all the same
     got = []
-    for k in range(6):
-        s = streams[k % 2]
+    for k in range(FRAMES):
+        s = streams[k % F]
         buf = pipe.acquire(s)
         with torch.cuda.stream(s):
             buf[:rows] = k * 10 + rank
@@ -43,10 +45,11 @@ for dtype in (torch.uint8, torch.float32):
     got += pipe.drain()
     torch.cuda.synchronize()
     if rank == 0:
-        assert len(got) == 6, len(got)
+        assert len(got) == FRAMES, len(got)
         for k, img in enumerate(got):
             vals = sorted(set(img.reshape(-1).tolist()))
-            assert vals == [k * 10, k * 10 + 1], (k, vals)
-        print("pipeline ok with", dtype, flush=True)
+            want = sorted({(k * 10 + r) % 256 if dtype == torch.uint8 else k * 10 + r for r in range(world)})
+            assert vals == want, (k, vals, want)
+        print("pipeline ok with", dtype, "-", world, "rank(s),", F, "frames in flight", flush=True)
 dist.barrier()
 dist.destroy_process_group()
