@@ -649,22 +649,25 @@ __device__ __forceinline__ bool bin_row_owned(const FrameConst &fc, int by) {
 // atomicAdd(base + bin, 1) for every active lane, lanes of the wave that name the same bin sharing ONE atomic
 // (neighbouring faces land in the same bins, and atomics that cross the XCDs are what the binning passes pay for).
 // Returns the value the lane's own atomicAdd would have returned.  Every lane of the wave must call this.
+// The groups are found first (ballots only); then the leaders of ALL groups issue their atomics in one instruction,
+// so a step costs one round trip to the atomic unit, not one per distinct bin.
 __device__ __forceinline__ int shared_increment(int *base, int bin, bool active) {
     const int lane = (int)(threadIdx.x & 63);
+    const unsigned long long below = (1ull << lane) - 1ull;
     unsigned long long todo = __ballot(active);
-    int result = 0;
+    int leader_of = lane, rank = 0, size = 0;
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const int b = __shfl(bin, leader, 64);
         const bool mine = active && bin == b;
         const unsigned long long same = __ballot(mine);
-        int old = 0;
-        if (lane == leader) old = atomicAdd(base + b, (int)__popcll(same));
-        old = __shfl(old, leader, 64);
-        if (mine) result = old + (int)__popcll(same & ((1ull << lane) - 1ull));
+        if (mine) leader_of = leader, rank = (int)__popcll(same & below), size = (int)__popcll(same);
         todo &= ~same;
     }
-    return result;
+    int old = 0;
+    if (active && leader_of == lane) old = atomicAdd(base + bin, size);
+    old = __shfl(old, leader_of, 64);
+    return old + rank;
 }
 
 // AGG: the wave steps through its faces' bins together and shares the atomics.  It pays when the faces are small
