@@ -68,7 +68,7 @@ struct BinState {
 // runs through the whole list, one batch of four after the other, while a tree walk meets 10..35 boxes and a
 // few faces whatever the image size.  Measured crossover (69 K-face and 1.1 M-face scenes, 480x270 .. 4K):
 // bins win at 21 and 32 entries per bin, the tree at 46 and beyond.
-constexpr int kMaxAverageBinList = 38;
+constexpr int kMaxAverageBinList = 42;
 
 // Per-stage counters (one stage = one recursion level of one SSAA pass), zeroed once per frame.
 struct StageCounters {
