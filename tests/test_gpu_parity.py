@@ -665,3 +665,39 @@ def test_gather_pipeline_rehearsal_on_streams():
         assert img[0, 0, 0] == k
         img[0, 0, 0] = want[0, 0, 0]
         assert np.array_equal(img, want)
+
+
+@pytest.mark.parametrize("seed,size", [(0, (640, 480)), (1, (1920, 1080)), (2, (333, 777))])
+def test_faces_smaller_than_a_pixel_bins_and_grids_against_the_tree(seed, size):
+    """Dust: tens of thousands of faces of about a pixel and less, several per pixel.  Their projected boxes are
+    widened by a sixteenth of a pixel only (and their cells in the shadow grids by a sliver of a cell), so this is
+    where a candidate list that is too tight would lose a hit: screen bins and shadow grids against the tree walk,
+    bit for bit, also with sub-samples and a row partition."""
+    rng = np.random.default_rng(100 + seed)
+    n = 40000
+    centres = rng.uniform(-1.0, 1.0, (n, 1, 3)) * np.array([1.0, 1.0, 0.3])
+    extent = rng.choice([0.0004, 0.0015, 0.004, 0.012], (n, 1, 1))
+    tri = (centres + rng.uniform(-1.0, 1.0, (n, 3, 3)) * extent).astype(np.float32)
+    verts = tri.reshape(-1, 3)
+    faces = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    mats = [dict(ka=[0.1] * 3, kd=[0.2 + 0.2 * m, 0.9 - 0.2 * m, 0.5], ks=[0.0] * 3, shininess=8.0) for m in range(4)]
+    arrays = (verts, None, faces, rng.integers(0, 4, n).astype(np.int32), mats)
+    lights = [(-1.0, 1.0, 1.0), (0.7, 1.3, -0.4)]
+    W, H = size
+    kw = dict(arrays=arrays, lights=lights, soft_points=1, output="")
+    a = R.Flyscene(primary_rays=L.PRIMARY_RAYS_BINS, **kw).initialize(W, H)
+    b = R.Flyscene(primary_rays=L.PRIMARY_RAYS_TREE, shadow_rays=L.SHADOW_RAYS_TREE, **kw).initialize(W, H)
+    d = R.Flyscene(primary_rays=L.PRIMARY_RAYS_BINS, builder=L.BUILDER_DEVICE_LBVH, **kw).initialize(W, H)
+    assert a.info().shadow_grid_entries > 0 and d.info().shadow_grid_entries == a.info().shadow_grid_entries
+    for params in (dict(), dict(ssaa_level=2), dict(row_tile=16, num_parts=4, part=3)):
+        if W * H > 10**6 and "ssaa_level" in params:
+            continue
+        for f in (a, b, d):
+            f.set_params(max_reflections=0, **params)
+        ra, rb, rd = a.render(), b.render(), d.render()
+        assert ra["stats"].primary_path == 1 and rb["stats"].primary_path == 0
+        assert (ra["face_id"] >= 0).sum() > 200
+        for r in (ra, rd):
+            assert np.array_equal(r["face_id"], rb["face_id"]), (size, params)
+            assert np.array_equal(r["rgb"].view(np.uint32), rb["rgb"].view(np.uint32)), (size, params)
+            assert (r["stats"].rays_shadow, r["stats"].hits) == (rb["stats"].rays_shadow, rb["stats"].hits)
