@@ -239,6 +239,23 @@ int rtamd_render_device(rtamd_scene *scene, const rtamd_camera *cam, const rtamd
                         int32_t *face_id_dev, float *t_hit_dev, void *hip_stream);
 int rtamd_render_stats(rtamd_scene *scene, rtamd_stats *stats);
 
+/* rtamd_render_device for callers that cannot allocate: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same arguments, same results, but the
+ * work buffers of the frame (hit lists, ray queues, counters, screen bins) live in one static array of
+ * RTAMD_NOALLOC_WORKSPACE_BYTES that is part of the library's code object -- every GPU the library runs on holds
+ * that much until the process ends -- so the call allocates, frees and creates nothing: no hipMalloc, no events,
+ * no internal streams (everything is enqueued on hip_stream; RTAMD_FLAG_TIME_KERNELS is ignored).  The array's
+ * address is looked up when a scene is created on the device.
+ * Limit: a frame whose buffers exceed the array (about 200 + 2 * lights * samples_per_light bytes per pixel of the
+ * local image, rounded up to 8x8 tiles: 640x480 with 13 shadow rays per hit fits, 1920x1080 does not) is refused
+ * with RTAMD_ERR_LIMIT.  When the screen bins of the primary rays do not fit beside the rest, those rays walk the
+ * BVH instead (same image).
+ * All calls on one GPU share that GPU's array, whatever the scene: frames enqueued through this entry point must
+ * not overlap on a device (enqueue them on one stream, or order the streams); two that do race. */
+#define RTAMD_NOALLOC_WORKSPACE_BYTES (64u << 20)
+int rtamd_render_device_noalloc(rtamd_scene *scene, const rtamd_camera *cam, const rtamd_render_params *p, float *rgb_dev,
+                                int32_t *face_id_dev, float *t_hit_dev, void *hip_stream);
+
 /* The 8-bit image writePPMImage stores (utils/ppmIO.hpp:188-209): bytes_dev[i] = min(255, (int)(255 *
  * rgb_dev[i])) for `count` channel values, on the device and on hip_stream.  With several GPUs the ranks
  * can exchange these bytes instead of the floats: a quarter of the traffic, the same result.ppm.

@@ -10,6 +10,7 @@ LIB_PATH = os.environ.get("RTAMD_LIB") or os.path.join(_HERE, "lib", "librtamd.s
 OK, ERR_INVALID, ERR_HIP, ERR_LIMIT, ERR_NO_DEVICE = 0, 1, 2, 3, 4
 FACE_SPHERE, FACE_MISS = -1, -2
 FLAG_COUNT_WORK, FLAG_TIME_KERNELS, FLAG_SINGLE_STREAM = 1, 2, 4
+NOALLOC_WORKSPACE_BYTES = 64 << 20
 SHADOW_RAYS_AUTO, SHADOW_RAYS_TREE = 0, 1
 PRIMARY_RAYS_AUTO, PRIMARY_RAYS_TREE, PRIMARY_RAYS_BINS = 0, 1, 2
 BUILDER_HOST_SAH, BUILDER_DEVICE_LBVH = 0, 1
@@ -113,6 +114,7 @@ SYMBOLS = {
     "rtamd_render": (C.c_int, [_P, C.POINTER(Camera), C.POINTER(RenderParams), _fp, _ip, C.POINTER(Stats)]),
     "rtamd_render_device": (C.c_int, [_P, C.POINTER(Camera), C.POINTER(RenderParams), _P, _P, _P, _P]),
     "rtamd_render_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "rtamd_render_device_noalloc": (C.c_int, [_P, C.POINTER(Camera), C.POINTER(RenderParams), _P, _P, _P, _P]),
     "rtamd_quantize_ppm": (C.c_int, [_P, _P, C.c_uint64, _P]),
     "rtamd_assemble_rows": (C.c_int, [C.POINTER(RenderParams), _P, _P, C.c_int32, _P]),
     "rtfly_create": (C.c_int, [C.POINTER(_P)]),

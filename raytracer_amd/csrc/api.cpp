@@ -95,7 +95,9 @@ struct rtamd_scene {
     // the least recently used one is handed on), so frames enqueued on different streams may overlap on the GPU.
     FrameSlot slots[kMaxFrameSlots];
     int num_slots = 0;
-    int last_slot = -1; // slot of the most recent frame (what rtamd_render_stats reports)
+    FrameSlot static_slot;   // frames of rtamd_render_device_noalloc: work buffers in the library's static device array
+    char *scratch = nullptr; // that array's address on this scene's device
+    FrameSlot *last_frame_slot = nullptr; // slot of the most recent frame (what rtamd_render_stats reports)
     uint64_t clock = 0;
     rtamd_scene_info info{};
     bool bin_primary = true; // screen binning of the primary rays (rtamd_build_params::primary_rays)
@@ -128,54 +130,67 @@ int upload(void **dst, const std::vector<T> &src, uint64_t *bytes) {
     return RTAMD_OK;
 }
 
-// `slots` = ray slots of the local image = whole 8x8 tiles (a multiple of 64).
+// Lays the work buffers of one frame in flight out behind `base` and returns the bytes they take; with base == nullptr
+// nothing is written through `ws` but sizes, so the same code answers "how much" and "where".
+// `slots` = ray slots of the local image = whole 8x8 tiles (a multiple of 64); bins == 0: no screen bins.
+size_t layout_workspace(char *base, size_t slots, size_t nshadow, size_t bins, size_t ntris, Workspace &ws) {
+    const size_t cap = (slots + 255) & ~(size_t)255; // every plane starts 1 KiB aligned
+    const size_t head = 4096;                        // stage counters + work counters
+    static_assert(sizeof(StageCounters) * kMaxStages <= 2048, "counter block too small");
+    const size_t bin_capacity = bins ? std::min<size_t>(8 * ntris + (1u << 20), (size_t)1 << 30) : 0;
+    uintptr_t p = (uintptr_t)base + head;
+    auto take = [&](size_t bytes) {
+        char *at = (char *)p;
+        p += bytes;
+        return at;
+    };
+    auto align = [&](uintptr_t to) { p = (p + to - 1) & ~(to - 1); };
+    ws.stage = (StageCounters *)(uintptr_t)base;
+    ws.work = (WorkCounters *)((uintptr_t)base + 2048);
+    ws.bin_state = nullptr, ws.bin_count = nullptr, ws.bin_start = nullptr, ws.bin_entries = nullptr, ws.big = nullptr;
+    ws.bin_capacity = 0;
+    if (bins) { // right behind the counters: one memset clears all three at the start of a frame
+        ws.bin_state = (BinState *)take(256);
+        ws.bin_count = (int32_t *)take((bins + 256) * 4);
+        align(1024);
+    }
+    ws.slot_tri = (int32_t *)take(cap * 4);
+    ws.slot_t = (float *)take(cap * 4);
+    for (HitList &h : ws.hits) {
+        h.slot = (int32_t *)take(cap * 4);
+        h.tri = (int32_t *)take(cap * 4);
+        h.child = (int32_t *)take(cap * 4);
+        h.p = (float *)take(3 * cap * 4);
+    }
+    for (float *&q : ws.queue) q = (float *)take(10 * cap * 4);
+    for (uint8_t *&c : ws.clear) c = (uint8_t *)take(nshadow * cap);
+    if (bins) {
+        align(256);
+        ws.big = (int4 *)take((ntris + 1) * 16);
+        ws.bin_start = (int32_t *)take((bins + 256) * 4);
+        ws.bin_entries = (int32_t *)take(bin_capacity * 4);
+        ws.bin_capacity = (int32_t)bin_capacity;
+    }
+    ws.capacity = (int32_t)cap;
+    return (size_t)(p - (uintptr_t)base) + 1024;
+}
+
 int ensure_workspace(rtamd_scene *s, FrameSlot &fs, size_t slots, size_t bins_needed) {
     if (fs.block && (size_t)fs.ws.capacity >= slots && fs.bins >= (s->bin_primary ? bins_needed : 0)) return RTAMD_OK;
     if (fs.block) {
         HIP_TRY(hipFree(fs.block)); // waits for the device: no frame still reads the old block
         fs.block = nullptr;
     }
-    const size_t cap = (slots + 255) & ~(size_t)255; // every plane starts 1 KiB aligned
     const size_t nshadow = (size_t)s->ds.num_lights * (size_t)s->ds.spl;
-    const size_t planes = 2 /*slot tri, t*/ + 2 * 6 /*two hit lists: slot, tri, child, point*/ + 30 /*three queues*/;
-    const size_t head = 4096; // stage counters + work counters
-    // screen bins: sized for the whole image this workspace may see (the bins cover all rows, owned or not)
     const size_t ntris = (size_t)s->info.num_device_faces;
-    const size_t bin_capacity = s->bin_primary ? std::min<size_t>(8 * ntris + (1u << 20), (size_t)1 << 30) : 0;
-    const size_t bins = s->bin_primary ? bins_needed : 0;
-    const size_t bin_bytes = s->bin_primary ? 256 + (2 * bins + 512 + bin_capacity) * 4 + (ntris + 1) * 16 : 0;
-    const size_t total = head + planes * cap * 4 + 2 * nshadow * cap + bin_bytes + 1024;
+    const size_t bins = s->bin_primary ? bins_needed : 0; // sized for the whole image this workspace may see
+    int32_t *const feedback = fs.ws.bin_feedback;
+    Workspace sizes{};
+    const size_t total = layout_workspace(nullptr, slots, nshadow, bins, ntris, sizes);
     HIP_TRY(hipMalloc(&fs.block, total));
-    char *base = (char *)fs.block;
-    fs.ws.stage = (StageCounters *)base;
-    fs.ws.work = (WorkCounters *)(base + 2048);
-    static_assert(sizeof(StageCounters) * kMaxStages <= 2048, "counter block too small");
-    char *p = base + head;
-    if (s->bin_primary) { // right behind the counters: one memset clears all three at the start of a frame
-        fs.ws.bin_state = (BinState *)p, p += 256;
-        fs.ws.bin_count = (int32_t *)p, p += (bins + 256) * 4;
-        p = (char *)(((uintptr_t)p + 1023) & ~(uintptr_t)1023);
-    }
-    fs.ws.slot_tri = (int32_t *)p, p += cap * 4;
-    fs.ws.slot_t = (float *)p, p += cap * 4;
-    for (HitList &h : fs.ws.hits) {
-        h.slot = (int32_t *)p, p += cap * 4;
-        h.tri = (int32_t *)p, p += cap * 4;
-        h.child = (int32_t *)p, p += cap * 4;
-        h.p = (float *)p, p += 3 * cap * 4;
-    }
-    for (float *&q : fs.ws.queue) q = (float *)p, p += 10 * cap * 4;
-    for (uint8_t *&c : fs.ws.clear) c = (uint8_t *)p, p += nshadow * cap;
-    fs.ws.bin_entries = nullptr;
-    if (s->bin_primary) {
-        p = (char *)(((uintptr_t)p + 255) & ~(uintptr_t)255);
-        fs.ws.big = (int4 *)p, p += (ntris + 1) * 16;
-        fs.ws.bin_start = (int32_t *)p, p += (bins + 256) * 4;
-        fs.ws.bin_entries = (int32_t *)p, p += bin_capacity * 4;
-        fs.ws.bin_capacity = (int32_t)bin_capacity;
-        fs.bins = bins;
-    }
-    fs.ws.capacity = (int32_t)cap;
+    layout_workspace((char *)fs.block, slots, nshadow, bins, ntris, fs.ws);
+    fs.ws.bin_feedback = feedback;
+    fs.bins = bins;
     return RTAMD_OK;
 }
 
@@ -243,8 +258,33 @@ int acquire_slot(rtamd_scene *s, hipStream_t stream, FrameSlot **out) {
     FrameSlot &fs = s->slots[pick];
     fs.stream = stream;
     fs.stamp = ++s->clock;
-    s->last_slot = pick;
     *out = &fs;
+    return RTAMD_OK;
+}
+
+// ---- work buffers of rtamd_render_device_noalloc
+// One array per GPU, part of the library's code object: every device that loads the library holds its own copy
+// at its own address until the process ends.  Host code must never use the NAME as an address (on the host it is
+// a stand-in symbol); the device address is looked up once per device, with that device current, and kept.
+constexpr size_t kScratchBytes = (size_t)RTAMD_NOALLOC_WORKSPACE_BYTES;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+constexpr int kMaxDevices = 64;
+int scratch_pointer(int device, char **out) {
+    static std::mutex lock;
+    static char *per_device[kMaxDevices];
+    if (device < 0 || device >= kMaxDevices) return fail(RTAMD_ERR_LIMIT, "device ordinal %d outside 0..%d", device, kMaxDevices - 1);
+    std::lock_guard<std::mutex> guard(lock);
+    if (!per_device[device]) {
+        int current = -1;
+        HIP_TRY(hipGetDevice(&current));
+        if (current != device) return fail(RTAMD_ERR_INVALID, "device %d must be current to look up its work buffers (device %d is)", device, current);
+        void *ptr = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(RTAMD_ERR_HIP, "hipGetSymbolAddress returned a null address for the static work buffers");
+        per_device[device] = (char *)ptr;
+    }
+    *out = per_device[device];
     return RTAMD_OK;
 }
 
@@ -353,6 +393,10 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     rtamd_scene *s = new (std::nothrow) rtamd_scene();
     if (!s) return fail(RTAMD_ERR_INVALID, "out of host memory");
     s->device = dev;
+    if (scratch_pointer(dev, &s->scratch) != RTAMD_OK) {
+        delete s;
+        return RTAMD_ERR_HIP;
+    }
     s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
     // ---- host build
@@ -573,35 +617,41 @@ int rtamd_scene_get_info(const rtamd_scene *s, rtamd_scene_info *info) {
     return RTAMD_OK;
 }
 
-int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_render_params *p, float *rgb, int32_t *face_id, float *t_hit,
-                        void *hip_stream) {
-    int rc = check_params(s, cam, p);
-    if (rc != RTAMD_OK) return rc;
-    if (!rgb) return fail(RTAMD_ERR_INVALID, "null rgb output");
-    int dev = -1;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev != s->device) return fail(RTAMD_ERR_INVALID, "scene lives on device %d but device %d is current", s->device, dev);
-    hipStream_t stream = (hipStream_t)hip_stream;
+} // extern "C"
 
-    const int local_rows = rtamd_local_rows(p);
-    const size_t pixels = (size_t)local_rows * (size_t)p->width;
-    const int S = p->ssaa_level;
-    const int depths = (any_reflective(s, p->reflect_threshold) ? p->max_reflections : 0) + 1;
-    const int stages = S * S * depths;
-    if (stages > kMaxStages) return fail(RTAMD_ERR_LIMIT, "ssaa^2 * (max_reflections + 1) = %d exceeds %d", stages, kMaxStages);
-    s->have_frame = false;
-    if (pixels == 0) return RTAMD_OK;
-    const int tiles_x = (p->width + 7) / 8, tiles_y = (local_rows + 7) / 8;
-    const size_t slots = (size_t)tiles_x * (size_t)tiles_y * 64;
-    const size_t nshadow = (size_t)s->ds.num_lights * (size_t)s->ds.spl;
-    if (slots * (nshadow ? nshadow : 1) > (size_t)0x7f000000)
-        return fail(RTAMD_ERR_LIMIT, "%zu ray slots x %zu shadow rays per hit exceed the 2^31 work-item limit of one launch", slots, nshadow);
-    const int bins_x = (p->width + kBinPixels - 1) / kBinPixels, bins_y = (p->height + kBinPixels - 1) / kBinPixels;
-    FrameSlot *slot = nullptr;
-    if ((rc = acquire_slot(s, stream, &slot)) != RTAMD_OK) return rc;
-    FrameSlot &fs = *slot;
-    rc = ensure_workspace(s, fs, slots, (size_t)bins_x * (size_t)bins_y);
-    if (rc != RTAMD_OK) return rc;
+namespace {
+
+// What a frame of the given parameters needs; filled by frame_shape.
+struct FrameShape {
+    int local_rows = 0, S = 1, depths = 1, stages = 1, tiles_x = 0, tiles_y = 0, bins_x = 0, bins_y = 0;
+    size_t pixels = 0, slots = 0, nshadow = 0;
+};
+
+int frame_shape(const rtamd_scene *s, const rtamd_render_params *p, FrameShape &f) {
+    f.local_rows = rtamd_local_rows(p);
+    f.pixels = (size_t)f.local_rows * (size_t)p->width;
+    f.S = p->ssaa_level;
+    f.depths = (any_reflective(s, p->reflect_threshold) ? p->max_reflections : 0) + 1;
+    f.stages = f.S * f.S * f.depths;
+    if (f.stages > kMaxStages) return fail(RTAMD_ERR_LIMIT, "ssaa^2 * (max_reflections + 1) = %d exceeds %d", f.stages, kMaxStages);
+    f.tiles_x = (p->width + 7) / 8, f.tiles_y = (f.local_rows + 7) / 8;
+    f.slots = (size_t)f.tiles_x * (size_t)f.tiles_y * 64;
+    f.nshadow = (size_t)s->ds.num_lights * (size_t)s->ds.spl;
+    if (f.slots * (f.nshadow ? f.nshadow : 1) > (size_t)0x7f000000)
+        return fail(RTAMD_ERR_LIMIT, "%zu ray slots x %zu shadow rays per hit exceed the 2^31 work-item limit of one launch", f.slots, f.nshadow);
+    f.bins_x = (p->width + kBinPixels - 1) / kBinPixels, f.bins_y = (p->height + kBinPixels - 1) / kBinPixels;
+    return RTAMD_OK;
+}
+
+// Enqueues every launch of one frame on `stream` (and, for a reflective scene rendered on one caller stream, on the
+// two side streams), using the work buffers of `fs`.  `plain`: the caller may not allocate or create anything --
+// no timing events, no side streams (their events are created on demand), no completion event.
+int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const rtamd_camera *cam, const rtamd_render_params *p, float *rgb,
+                  int32_t *face_id, float *t_hit, hipStream_t stream, bool plain) {
+    int rc = RTAMD_OK;
+    const int local_rows = shape.local_rows, S = shape.S, depths = shape.depths, stages = shape.stages;
+    const int tiles_x = shape.tiles_x, tiles_y = shape.tiles_y, bins_x = shape.bins_x, bins_y = shape.bins_y;
+    const size_t pixels = shape.pixels, nshadow = shape.nshadow;
 
     FrameConst fc;
     std::memset(&fc, 0, sizeof fc);
@@ -673,7 +723,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     ws_frame.full_waves = forced_waves >= 0 ? forced_waves : s->num_slots > 1; // several caller streams: frames overlap
 
     const bool count = (p->flags & RTAMD_FLAG_COUNT_WORK) != 0;
-    const bool timed = (p->flags & RTAMD_FLAG_TIME_KERNELS) != 0;
+    const bool timed = !plain && (p->flags & RTAMD_FLAG_TIME_KERNELS) != 0;
     size_t open_slot = 0;
     hipStream_t stream_of_launch = stream; // timing events are recorded on the stream their kernel runs on
     auto begin = [&](int kind) -> int {
@@ -712,7 +762,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     // Side streams only for a scene that is rendered on ONE caller stream.  A caller with several streams overlaps
     // whole frames instead, each entirely on its own stream: the streams in use then outnumber the hardware
     // queues, and waits between streams that share a queue are what must not happen (see side_streams).
-    const bool two_streams = depths > 1 && !serial && (p->flags & RTAMD_FLAG_SINGLE_STREAM) == 0 && s->num_slots == 1;
+    const bool two_streams = !plain && depths > 1 && !serial && (p->flags & RTAMD_FLAG_SINGLE_STREAM) == 0 && s->num_slots == 1;
     hipStream_t geo = stream, deep = stream;
     if (two_streams) {
         SideStreams *side = nullptr;
@@ -784,7 +834,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
         if ((rc = end()) != RTAMD_OK) return rc;
     }
     if (timed) HIP_TRY(hipEventRecord(s->events[frame_slot].stop, stream));
-    HIP_TRY(hipEventRecord(fs.done, stream));
+    if (fs.done) HIP_TRY(hipEventRecord(fs.done, stream));
     fs.used = true;
     HIP_TRY(hipGetLastError());
 
@@ -793,9 +843,67 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     s->last_depths = depths;
     s->last_primary = (uint64_t)pixels * (uint64_t)(S * S);
     s->last_stream = stream;
+    s->last_frame_slot = &fs;
     s->have_frame = true;
     return RTAMD_OK;
 }
+
+} // namespace
+
+extern "C" {
+
+int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_render_params *p, float *rgb, int32_t *face_id, float *t_hit,
+                        void *hip_stream) {
+    int rc = check_params(s, cam, p);
+    if (rc != RTAMD_OK) return rc;
+    if (!rgb) return fail(RTAMD_ERR_INVALID, "null rgb output");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != s->device) return fail(RTAMD_ERR_INVALID, "scene lives on device %d but device %d is current", s->device, dev);
+    hipStream_t stream = (hipStream_t)hip_stream;
+    FrameShape shape;
+    if ((rc = frame_shape(s, p, shape)) != RTAMD_OK) return rc;
+    s->have_frame = false;
+    if (shape.pixels == 0) return RTAMD_OK;
+    FrameSlot *slot = nullptr;
+    if ((rc = acquire_slot(s, stream, &slot)) != RTAMD_OK) return rc;
+    rc = ensure_workspace(s, *slot, shape.slots, (size_t)shape.bins_x * (size_t)shape.bins_y);
+    if (rc != RTAMD_OK) return rc;
+    return enqueue_frame(s, *slot, shape, cam, p, rgb, face_id, t_hit, stream, /*plain=*/false);
+}
+
+int rtamd_render_device_noalloc(rtamd_scene *s, const rtamd_camera *cam, const rtamd_render_params *p, float *rgb, int32_t *face_id,
+                                float *t_hit, void *hip_stream) {
+    int rc = check_params(s, cam, p);
+    if (rc != RTAMD_OK) return rc;
+    if (!rgb) return fail(RTAMD_ERR_INVALID, "null rgb output");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != s->device) return fail(RTAMD_ERR_INVALID, "scene lives on device %d but device %d is current", s->device, dev);
+    FrameShape shape;
+    if ((rc = frame_shape(s, p, shape)) != RTAMD_OK) return rc;
+    s->have_frame = false;
+    if (shape.pixels == 0) return RTAMD_OK;
+    // Work buffers: laid out in the device's static array instead of a hipMalloc'ed block.  Screen bins for the primary
+    // rays only when they fit as well (otherwise those rays walk the tree: same image).
+    const size_t ntris = (size_t)s->info.num_device_faces;
+    const size_t bins = s->bin_primary ? (size_t)shape.bins_x * (size_t)shape.bins_y : 0;
+    Workspace sizes{};
+    const size_t need_plain = layout_workspace(nullptr, shape.slots, shape.nshadow, 0, ntris, sizes);
+    if (need_plain > kScratchBytes)
+        return fail(RTAMD_ERR_LIMIT, "a frame of %d x %d pixels with %zu shadow rays per hit needs %zu bytes of work buffers; "
+                    "rtamd_render_device_noalloc holds %zu (use rtamd_render_device)", p->width, shape.local_rows, shape.nshadow, need_plain, kScratchBytes);
+    const bool with_bins = bins > 0 && layout_workspace(nullptr, shape.slots, shape.nshadow, bins, ntris, sizes) <= kScratchBytes;
+    char *base = s->scratch; // looked up when the scene was created
+    if (!base && (rc = scratch_pointer(dev, &base)) != RTAMD_OK) return rc;
+    FrameSlot &fs = s->static_slot;
+    layout_workspace(base, shape.slots, shape.nshadow, with_bins ? bins : 0, ntris, fs.ws);
+    fs.block = base;
+    fs.bins = with_bins ? bins : 0;
+    fs.stream = (hipStream_t)hip_stream;
+    return enqueue_frame(s, fs, shape, cam, p, rgb, face_id, t_hit, (hipStream_t)hip_stream, /*plain=*/true);
+}
+
 
 int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
     if (!s || !st) return fail(RTAMD_ERR_INVALID, "null scene or stats");
@@ -803,7 +911,8 @@ int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
     if (!s->have_frame) return RTAMD_OK;
     for (int i = 0; i < s->num_slots; ++i) // timing events of every frame in flight must have completed
         if (s->slots[i].used) HIP_TRY(hipEventSynchronize(s->slots[i].done));
-    const Workspace &ws_last = s->slots[s->last_slot].ws;
+    if (s->last_frame_slot == &s->static_slot) HIP_TRY(hipStreamSynchronize(s->last_stream)); // that slot has no event
+    const Workspace &ws_last = s->last_frame_slot->ws;
     std::vector<StageCounters> sc((size_t)kMaxStages);
     WorkCounters wc[3];
     HIP_TRY(hipMemcpy(sc.data(), ws_last.stage, sizeof(StageCounters) * kMaxStages, hipMemcpyDeviceToHost));
@@ -820,7 +929,7 @@ int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
         st->tri_plane[k] = wc[k].tri_plane;
         st->tri_edge[k] = wc[k].tri_edge;
     }
-    if (s->slots[s->last_slot].binned) {
+    if (s->last_frame_slot->binned) {
         BinState bs;
         HIP_TRY(hipMemcpy(&bs, ws_last.bin_state, sizeof bs, hipMemcpyDeviceToHost));
         st->bin_entries = (uint32_t)bs.total;

@@ -179,9 +179,10 @@ class Flyscene:
         p = params if params is not None else self.params
         return self.lib.rtamd_local_rows(C.byref(p))
 
-    def render_device(self, rgb, face_id=None, t_hit=None, params=None, camera=None, stream=None):
+    def render_device(self, rgb, face_id=None, t_hit=None, params=None, camera=None, stream=None, noalloc=False):
         """Enqueue one frame on `stream` (a torch.cuda.Stream, default: torch's current stream) writing
-        into torch CUDA tensors.  No host synchronisation."""
+        into torch CUDA tensors.  No host synchronisation.  noalloc=True goes through
+        rtamd_render_device_noalloc (work buffers in the library's static device array, nothing allocated)."""
         import torch
 
         p = params if params is not None else self.params
@@ -195,10 +196,11 @@ class Flyscene:
         if t_hit is not None and (t_hit.dtype != torch.float32 or not t_hit.is_cuda or not t_hit.is_contiguous() or t_hit.numel() < need):
             raise ValueError("t_hit must be a contiguous float32 CUDA tensor with at least %d elements" % need)
         s = stream if stream is not None else torch.cuda.current_stream(rgb.device)
-        L.check(self.lib.rtamd_render_device(self.scene, C.byref(cam), C.byref(p), C.c_void_p(rgb.data_ptr()),
-                                             C.c_void_p(face_id.data_ptr()) if face_id is not None else None,
-                                             C.c_void_p(t_hit.data_ptr()) if t_hit is not None else None,
-                                             C.c_void_p(s.cuda_stream)), "rtamd_render_device")
+        entry = self.lib.rtamd_render_device_noalloc if noalloc else self.lib.rtamd_render_device
+        L.check(entry(self.scene, C.byref(cam), C.byref(p), C.c_void_p(rgb.data_ptr()),
+                      C.c_void_p(face_id.data_ptr()) if face_id is not None else None,
+                      C.c_void_p(t_hit.data_ptr()) if t_hit is not None else None,
+                      C.c_void_p(s.cuda_stream)), "rtamd_render_device_noalloc" if noalloc else "rtamd_render_device")
 
     def stats(self):
         st = L.Stats()
