@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=25,
+                    help="the timed region of K steps is run this many times, each bracketed by barrier + synchronize; the line "
+                         "reports the median repeat as ms_per_step / value and the extremes beside it")
     ap.add_argument("--workload", default=None, help="default: bunny_1080p (1 GPU) / field_4k (several GPUs)")
     ap.add_argument("--size", default=None, help="WxH: render the workload at another image size (experiments; the line names it)")
     ap.add_argument("--row-tile", type=int, default=16)
@@ -82,8 +85,9 @@ def parse():
     ap.add_argument("--force-pipeline", action="store_true",
                     help="run the several-GPU code path (gather pipeline, both payloads, single-GPU comparison) on one GPU: a rehearsal "
                          "of everything but the collective itself")
-    ap.add_argument("--gather", choices=("u8", "f32"), default="u8",
-                    help="what the ranks send to rank 0: the 8-bit pixels the reference writes to result.ppm, or the float framebuffer")
+    ap.add_argument("--gather", choices=("u8", "f32"), default="f32",
+                    help="what the ranks send to rank 0: the float framebuffer (pixel_data, what the 1e-3 parity bar is stated on), or "
+                         "the 8-bit pixels the reference writes to result.ppm (a quarter of the bytes; timed as other_gather)")
     ap.add_argument("--builder", type=int, default=0, help="0 = host SAH builder, 1 = on-GPU Morton-order builder")
     ap.add_argument("--shadow-rays", type=int, default=0, help="0 = candidate grids when possible, 1 = shadow rays walk the BVH")
     ap.add_argument("--primary-rays", type=int, default=0, help="0 = screen binning, 1 = primary rays walk the BVH")
@@ -129,6 +133,7 @@ def cpu_baseline(w, cam, budget_s):
         "value": round(res.rays / res.seconds / 1e6, 4),
         "unit": "Mrays/s",
         "cores": threads,
+        "host_cores": os.cpu_count(),
         "kind": "port",
         "sample": "every %d-th image row of the same frame, %d time(s) (%d rays, %.1f s), oracle built -O3 -ffast-math -march=x86-64-v3, "
                   "rows interleaved over %d threads as the reference does" % (step, reps, res.rays, res.seconds, threads),
@@ -167,6 +172,53 @@ def pmc_traffic(workload, kernel_key):
     if fetch is None or write is None:
         return None, None
     return (2.0 * fetch + write) * 1024.0, os.path.basename(best)
+
+
+def profile_table(workload):
+    """Per-kernel figures from the committed profiles of this workload, so that the line shows every kernel and not
+    only the one `roofline` describes: wave-level VALU instructions and active lanes per VALU instruction
+    (SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU), bytes at the L2's memory side per launch
+    ((2 * FETCH_SIZE + WRITE_SIZE) KiB) from profiles/*_pmc_<workload>.txt, and with the average launch duration of
+    profiles/*_kernel_stats_<workload>_serial.csv (every kernel alone on the GPU) the fabric-side GB/s."""
+    import csv
+    import glob
+    import re
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    pmc = sorted(glob.glob(os.path.join(here, "*_pmc_%s.txt" % workload)))
+    if not pmc:
+        return None
+    counters, current = {}, None
+    for line in open(pmc[-1]):
+        if not line.startswith(" "):
+            current = line.strip()
+            counters[current] = {}
+            continue
+        m = re.match(r"\s+(\S+)\s+mean\s+([0-9.]+)", line)
+        if m and current:
+            counters[current][m.group(1)] = float(m.group(2))
+    avg_us = {}
+    stats = sorted(glob.glob(os.path.join(here, "*_kernel_stats_%s_serial.csv" % workload)))
+    if stats:
+        for row in csv.DictReader(open(stats[-1])):
+            m = re.search(r"(\w+_kernel(?:<[^>]*>)?)\(", row["Name"])
+            if m:
+                avg_us[m.group(1)] = float(row["AverageNs"]) / 1e3
+    table = {}
+    for kern, c in sorted(counters.items()):
+        if "true>" in kern.replace(" ", "") and kern.startswith(("walk", "shadow", "raster")):
+            continue  # the instrumented (work-counting) variants are not part of a timed frame
+        if "SQ_INSTS_VALU" not in c:
+            continue
+        row = {"valu_wave_insts": round(c["SQ_INSTS_VALU"]),
+               "lanes_per_valu_inst": round(c.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(c.get("SQ_ACTIVE_INST_VALU", 0.0), 1.0), 1)}
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            row["fabric_bytes"] = round((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0)
+            if kern in avg_us:
+                row["avg_us_alone"] = round(avg_us[kern], 1)
+                row["fabric_GBs"] = round(row["fabric_bytes"] / avg_us[kern] / 1e3, 1)
+        table[kern] = row
+    return {"per_launch": table, "source": [os.path.basename(pmc[-1])] + ([os.path.basename(stats[-1])] if stats else [])}
 
 
 def main():
@@ -275,11 +327,15 @@ def main():
     for _ in range(a.warmup):
         frame(timed)
     sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        frame(timed)
-    sync()
-    elapsed = time.perf_counter() - t0
+    # The timed region: exactly K steps between barrier + synchronize on both sides, repeated; a K-step region of a
+    # sub-millisecond frame is a few milliseconds long, so one sample of it is not a measurement.
+    repeat_s = []
+    for _ in range(max(1, a.repeats)):
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            frame(timed)
+        sync()
+        repeat_s.append(time.perf_counter() - t0)
     st = fly.stats()
     # ---- the same frame again, one at a time on one stream, with HIP events around every launch: per-kernel
     # durations for the roofline.  Outside the timed region: the events cost about a tenth of a frame, and with
@@ -293,6 +349,33 @@ def main():
         torch.cuda.synchronize(dev)
         st = fly.stats()
         del scratch
+
+    # ---- one frame alone, as a caller with a single view gets it: a second scene object, rendered on ONE stream (the library
+    # then spreads the deeper stages of a reflective frame over its side streams and narrower waves), each frame enqueued
+    # on an idle GPU and waited for; wall clock from the call to the end of the frame, and the frame's own HIP events
+    fly1 = None
+    single = None
+    if world == 1 and not a.force_pipeline:
+        fly1, _, cam1 = workloads.make_flyscene(w, max_leaf_faces=a.max_leaf, sah_bins=a.sah_bins, shadow_rays=a.shadow_rays,
+                                                primary_rays=a.primary_rays, builder=a.builder)
+        lone = tiles.part_params(base, 1, 0)
+        lone.flags = L.FLAG_TIME_KERNELS
+        buf1 = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        for _ in range(5):
+            fly1.render_device(buf1, params=lone, camera=cam, stream=streams[0])
+            torch.cuda.synchronize(dev)
+        fly1.stats()
+        wall = []
+        for _ in range(max(25, a.repeats)):
+            t0 = time.perf_counter()
+            fly1.render_device(buf1, params=lone, camera=cam, stream=streams[0])
+            torch.cuda.synchronize(dev)
+            wall.append((time.perf_counter() - t0) * 1e3)
+        st1 = fly1.stats()
+        wall.sort()
+        single = {"wall_ms": round(wall[len(wall) // 2], 4), "wall_ms_min": round(wall[0], 4), "wall_ms_max": round(wall[-1], 4),
+                  "events_ms": round(st1.ms_frames / max(st1.frames, 1), 4), "frames": len(wall)}
+        del buf1
 
     # ---- the same frames with the other payload of the gather (floats if bytes were timed above, or the reverse)
     other_elapsed = None
@@ -308,8 +391,8 @@ def main():
         sync(other_flush)
         other_elapsed = time.perf_counter() - t0
 
-    # ---- reduce over ranks: slowest rank's time, all ranks' rays
-    t_el = torch.tensor([elapsed, other_elapsed or 0.0], dtype=torch.float64, device=dev)
+    # ---- reduce over ranks: slowest rank's time of every repeat, all ranks' rays
+    t_el = torch.tensor(repeat_s + [other_elapsed or 0.0], dtype=torch.float64, device=dev)
     rays = torch.tensor([st.rays_primary, st.rays_shadow, st.rays_bounce], dtype=torch.float64, device=dev)
     kern = torch.tensor([st.ms_trace, st.ms_shadow, st.launches_trace, st.launches_shadow, st.ms_compact, st.ms_shade, st.ms_frames,
                          st.ms_raster, st.launches_raster], dtype=torch.float64, device=dev)
@@ -323,10 +406,11 @@ def main():
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
     else:
         kmax = kern
-    elapsed, other_elapsed = float(t_el[0].item()), float(t_el[1].item())
+    repeat_ms = sorted(float(x) / a.steps * 1e3 for x in t_el[:-1].tolist())
+    other_elapsed = float(t_el[-1].item())
     rays_frame = float(rays.sum().item())
-    ms_per_step = elapsed / a.steps * 1e3
-    value = rays_frame * a.steps / elapsed / 1e6
+    ms_per_step = repeat_ms[len(repeat_ms) // 2] if len(repeat_ms) % 2 else 0.5 * (repeat_ms[len(repeat_ms) // 2 - 1] + repeat_ms[len(repeat_ms) // 2])
+    value = rays_frame / ms_per_step / 1e3
 
     if rank == 0:
         out = {
@@ -337,13 +421,19 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "repeats": len(repeat_ms),
+            "ms_per_step_min": round(repeat_ms[0], 4),
+            "ms_per_step_max": round(repeat_ms[-1], 4),
+            "frame_ms_single": None if single is None else single["wall_ms"],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic" if w["scene"] != "bunny" else "reference scene (bunny.ply converted to OBJ), default camera",
+            "data": ("synthetic" if w["scene"] != "bunny" else
+                     "reference scene (bunny.ply converted to OBJ), default camera" +
+                     (", material modified: Ks raised from 0.1 to %g so that reflection rays occur" % w["ks"] if w.get("ks") is not None else "")),
             "config": {
-                "workload": name, "width": W, "height": H, "triangles": int(info.num_faces), "lights": len(w["lights"]),
+                "workload": name, "material_override": ({"ks": w["ks"]} if w.get("ks") is not None else None), "width": W, "height": H, "triangles": int(info.num_faces), "lights": len(w["lights"]),
                 "samples_per_light": 1 + w["soft_points"], "max_reflections": w["max_reflections"],
                 "rays_per_frame": {"primary": int(rays[0].item()), "shadow": int(rays[1].item()), "bounce": int(rays[2].item())},
                 "parallelism": ("one GPU, no exchange" if world == 1 else
@@ -382,12 +472,17 @@ def main():
             # bytes: the caches serve the re-reads.
             ach_b = bytes_launch / (per_launch_ms * 1e-3) / 1e9
             traffic, traffic_src = pmc_traffic(name, (closest_key, shadow_key, "raster_kernel<false>")[k])
-            out["roofline"] = {"kernel": kname, "bound": "hbm", "achieved": round(ach_b, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            # What binds it is neither roofline: a closest-hit walk is a chain of dependent fetches per ray (latency), the list
+            # kernels issue VALU work at a third of the lanes; the fractions against both peaks are reported all the same.
+            out["roofline"] = {"kernel": kname, "bound": "latency" if k == 0 else "valu_issue", "roofline": "hbm",
+                               "achieved": round(ach_b, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                "frac": round(ach_b / PEAK_HBM_GBS, 4), "traffic": None if traffic is None else round(traffic),
                                "algorithmic_bytes_per_launch": round(bytes_launch),
                                "avg_launch_ms": round(per_launch_ms, 4), "launches_per_frame": launches_per_frame,
                                "share_of_frame": round(group_ms[k] / max(kmax[6].item(), 1e-9), 3),
-                               "note": "algorithmic bytes are mostly served by L2 / Infinity Cache; the scene is %.1f MB" % (info.device_bytes / 1e6)}
+                               "note": "algorithmic bytes are mostly served by L2 / Infinity Cache (the scene is %.1f MB); avg_launch_ms: HIP events, "
+                                       "one frame at a time on one stream after the timed region, kernels in the form the timed region runs "
+                                       "them but each alone on the GPU (in the timed region %d frames overlap)" % (info.device_bytes / 1e6, in_flight)}
             if traffic is not None:
                 out["roofline"]["traffic_unit"] = "bytes/launch at the L2's memory side, (2*FETCH_SIZE + WRITE_SIZE) KiB, from profiles/" + traffic_src
             ach = flops_launch / (per_launch_ms * 1e-3) / 1e12
@@ -400,26 +495,49 @@ def main():
                               "tests_per_ray": {"box": round(float(wk[0::3].sum().item()) / rays_frame, 2),
                                                 "tri_plane": round(float(wk[1::3].sum().item()) / rays_frame, 2),
                                                 "tri_edge": round(float(wk[2::3].sum().item()) / rays_frame, 2)}}
+        table = profile_table(name)
+        if table is not None:
+            out["kernels_profiled"] = table
+        if single is not None:
+            single["note"] = ("one frame at a time on one stream of an otherwise idle GPU: host call to end of frame (wall_ms) and first "
+                              "to last launch of the frame by HIP events (events_ms); ms_per_step is the throughput figure, with "
+                              "%d frames in flight" % in_flight)
+            out["single_frame"] = single
         if world == 1:
             # the same frame through the blocking host-buffer entry point (upload of nothing, download of
             # rgb + face ids over PCIe): reported beside `value`, never as `value`
             plain = tiles.part_params(base, 1, 0)
-            h_rgb = np.zeros((H, W, 3), np.float32)
-            h_fid = np.zeros((H, W), np.int32)
             h_st = L.Stats()
             lib = L.lib()
 
-            def host_frame():
-                L.check(lib.rtamd_render(fly.scene, C.byref(cam), C.byref(plain), h_rgb.ctypes.data_as(C.POINTER(C.c_float)),
-                                         h_fid.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(h_st)), "rtamd_render")
+            def host_ms(rgb_ptr, fid_ptr):
+                def host_frame():
+                    L.check(lib.rtamd_render((fly1 or fly).scene, C.byref(cam), C.byref(plain), C.cast(rgb_ptr, C.POINTER(C.c_float)),
+                                             C.cast(fid_ptr, C.POINTER(C.c_int32)), C.byref(h_st)), "rtamd_render")
 
-            host_frame()
-            t0 = time.perf_counter()
-            for _ in range(5):
                 host_frame()
-            host_ms = (time.perf_counter() - t0) / 5 * 1e3
-            out["host_boundary"] = {"ms_per_frame": round(host_ms, 3), "Mrays_per_s": round(rays_frame / host_ms / 1e3, 1),
-                                    "note": "rtamd_render with host output buffers, PCIe download included"}
+                host_frame()
+                ts = []
+                for _ in range(15):
+                    t0 = time.perf_counter()
+                    host_frame()
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                return sorted(ts)[len(ts) // 2]
+
+            h_rgb = np.zeros((H, W, 3), np.float32)
+            h_fid = np.zeros((H, W), np.int32)
+            pageable_ms = host_ms(h_rgb.ctypes.data, h_fid.ctypes.data)
+            p_rgb, p_fid = C.c_void_p(), C.c_void_p()
+            L.check(lib.rtamd_host_alloc(C.byref(p_rgb), H * W * 12), "rtamd_host_alloc")
+            L.check(lib.rtamd_host_alloc(C.byref(p_fid), H * W * 4), "rtamd_host_alloc")
+            locked_ms = host_ms(p_rgb.value, p_fid.value)
+            lib.rtamd_host_free(p_rgb)
+            lib.rtamd_host_free(p_fid)
+            out["host_boundary"] = {"ms_per_frame": round(locked_ms, 3), "Mrays_per_s": round(rays_frame / locked_ms / 1e3, 1),
+                                    "ms_per_frame_pageable_buffers": round(pageable_ms, 3),
+                                    "note": "rtamd_render (blocking, one frame at a time) with host output buffers, PCIe download of rgb + face "
+                                            "ids (%.1f MB) included; ms_per_frame: buffers from rtamd_host_alloc (page-locked), the other figure: "
+                                            "ordinary malloc'ed buffers" % (H * W * 16 / 1e6)}
         if piped:
             out["other_gather"] = {"payload": "float32" if a.gather == "u8" else "8-bit (PPM pixels)",
                                    "ms_per_step": round(other_elapsed / a.steps * 1e3, 4),
@@ -443,6 +561,8 @@ def main():
         if world == 1 and a.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(w, cam, a.cpu_seconds)
             out["gpu_over_cpu"] = round(value / max(out["cpu_baseline"]["value"], 1e-9), 1)
+            out["gpu_over_cpu_note"] = ("value / cpu_baseline.value: one GPU against %d host threads (the GPU box's CPU share; the machine "
+                                        "has %d)" % (out["cpu_baseline"]["cores"], os.cpu_count() or 0))
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -224,6 +224,12 @@ int32_t rtamd_global_row(const rtamd_render_params *p, int32_t local_row);
 int rtamd_render(rtamd_scene *scene, const rtamd_camera *cam, const rtamd_render_params *p, float *rgb,
                  int32_t *face_id, rtamd_stats *stats);
 
+/* Page-locked host memory for the output planes of rtamd_render: the download then goes straight into the caller's
+ * buffer at the link's rate (any page-locked buffer does: hipHostMalloc, hipHostRegister); pageable buffers work too
+ * and cost an extra host copy.  Stands where the reference allocates pixel_data (src/flyscene.cpp:399-403). */
+int rtamd_host_alloc(void **ptr, uint64_t bytes);
+int rtamd_host_free(void *ptr);
+
 /* Same work, enqueued on `hip_stream` (a hipStream_t; NULL = default stream) without any host
  * synchronisation; outputs are DEVICE pointers on the scene's device (face_id, t_hit may be NULL;
  * t_hit = local_rows*width floats, primary hit distance, 0 on a miss).  rtamd_render_stats()

@@ -108,6 +108,8 @@ struct rtamd_scene {
     float *d_rgb = nullptr;
     int32_t *d_face = nullptr;
     size_t staging_pixels = 0;
+    void *h_staging = nullptr; // page-locked host memory the planes are downloaded into when the caller's buffers are pageable
+    size_t h_staging_bytes = 0;
     // bookkeeping of the most recent frame
     bool have_frame = false;
     rtamd_render_params last{};
@@ -603,6 +605,7 @@ int rtamd_scene_destroy(rtamd_scene *s) {
         if (fs.feedback) (void)hipHostFree((void *)fs.feedback);
         for (hipEvent_t e : fs.sync) (void)hipEventDestroy(e);
     }
+    if (s->h_staging) (void)hipHostFree(s->h_staging);
     for (TimedLaunch &t : s->events) {
         (void)hipEventDestroy(t.start);
         (void)hipEventDestroy(t.stop);
@@ -952,6 +955,18 @@ int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
     return RTAMD_OK;
 }
 
+int rtamd_host_alloc(void **out, uint64_t bytes) {
+    if (!out) return fail(RTAMD_ERR_INVALID, "null output pointer");
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, bytes ? (size_t)bytes : 64, hipHostMallocDefault));
+    return RTAMD_OK;
+}
+
+int rtamd_host_free(void *ptr) {
+    if (ptr) HIP_TRY(hipHostFree(ptr));
+    return RTAMD_OK;
+}
+
 int rtamd_render(rtamd_scene *s, const rtamd_camera *cam, const rtamd_render_params *p, float *rgb, int32_t *face_id, rtamd_stats *stats) {
     int rc = check_params(s, cam, p);
     if (rc != RTAMD_OK) return rc;
@@ -969,11 +984,48 @@ int rtamd_render(rtamd_scene *s, const rtamd_camera *cam, const rtamd_render_par
         HIP_TRY(hipMalloc((void **)&s->d_face, pixels * 4));
         s->staging_pixels = pixels;
     }
+    // Download: one asynchronous copy per plane behind the frame, one wait.  Into the caller's buffer when that is
+    // page-locked (rtamd_host_alloc, hipHostMalloc, hipHostRegister: the copy then runs at the link's rate), otherwise
+    // into page-locked buffers of the scene and from there with a few host threads (a pageable hipMemcpy stages
+    // through small bounce buffers and was four fifths of this call).
+    auto pinned = [](const void *ptr) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+            (void)hipGetLastError(); // an ordinary host pointer is reported as an error
+            return false;
+        }
+        return attr.type == hipMemoryTypeHost;
+    };
+    const bool rgb_direct = pinned(rgb), face_direct = face_id && pinned(face_id);
+    const size_t need = (rgb_direct ? 0 : pixels * 12) + (face_id && !face_direct ? pixels * 4 : 0);
+    if (s->h_staging_bytes < need) {
+        if (s->h_staging) HIP_TRY(hipHostFree(s->h_staging));
+        s->h_staging = nullptr, s->h_staging_bytes = 0;
+        HIP_TRY(hipHostMalloc(&s->h_staging, need, hipHostMallocDefault));
+        s->h_staging_bytes = need;
+    }
+    char *const stage_rgb = (char *)s->h_staging, *const stage_face = stage_rgb + (rgb_direct ? 0 : pixels * 12);
     rc = rtamd_render_device(s, cam, p, s->d_rgb, face_id ? s->d_face : nullptr, nullptr, nullptr);
     if (rc != RTAMD_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(rgb_direct ? (void *)rgb : (void *)stage_rgb, s->d_rgb, pixels * 12, hipMemcpyDeviceToHost, nullptr));
+    if (face_id) HIP_TRY(hipMemcpyAsync(face_direct ? (void *)face_id : (void *)stage_face, s->d_face, pixels * 4, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
-    HIP_TRY(hipMemcpy(rgb, s->d_rgb, pixels * 12, hipMemcpyDeviceToHost));
-    if (face_id) HIP_TRY(hipMemcpy(face_id, s->d_face, pixels * 4, hipMemcpyDeviceToHost));
+    auto host_copy = [](void *dst, const void *src, size_t bytes) {
+        const size_t workers = bytes >= ((size_t)4 << 20) ? 4 : 1;
+        if (workers == 1) {
+            std::memcpy(dst, src, bytes);
+            return;
+        }
+        std::vector<std::thread> pool;
+        const size_t chunk = ((bytes / workers) + 4095) & ~(size_t)4095;
+        for (size_t w = 0; w < workers; ++w) {
+            const size_t a = std::min(bytes, w * chunk), b = std::min(bytes, (w + 1) * chunk);
+            if (b > a) pool.emplace_back([=] { std::memcpy((char *)dst + a, (const char *)src + a, b - a); });
+        }
+        for (std::thread &t : pool) t.join();
+    };
+    if (!rgb_direct) host_copy(rgb, stage_rgb, pixels * 12);
+    if (face_id && !face_direct) host_copy(face_id, stage_face, pixels * 4);
     if (stats) return rtamd_render_stats(s, stats);
     return RTAMD_OK;
 }

@@ -807,8 +807,19 @@ int Flyscene::raytraceScene() {
     full.num_parts = 1, full.part = 0;
     const rtamd_render_params saved = params;
     params = full;
-    std::vector<float> pixel_data((size_t)size[0] * size[1] * 3);
-    const int rc = render(pixel_data.data(), nullptr, nullptr);
+    // pixel_data (src/flyscene.cpp:399-403) in page-locked memory: the frame is downloaded straight into it
+    void *locked = nullptr;
+    int rc = rtamd_host_alloc(&locked, (uint64_t)size[0] * size[1] * 3 * sizeof(float));
+    if (rc != RTAMD_OK) {
+        params = saved;
+        return rc;
+    }
+    struct Release {
+        void *p;
+        ~Release() { rtamd_host_free(p); }
+    } release{locked};
+    float *const pixel_data_ptr = (float *)locked;
+    rc = render(pixel_data_ptr, nullptr, nullptr);
     params = saved;
     if (rc != RTAMD_OK) return rc;
     auto ends_with = [&](const char *suffix) {
@@ -817,7 +828,7 @@ int Flyscene::raytraceScene() {
     };
     const bool binary = ends_with(".p6.ppm") || ends_with(".pnm");
     if (!output_path.empty() &&
-        !(binary ? write_ppm_binary(output_path, pixel_data.data(), size[0], size[1]) : write_ppm(output_path, pixel_data.data(), size[0], size[1])))
+        !(binary ? write_ppm_binary(output_path, pixel_data_ptr, size[0], size[1]) : write_ppm(output_path, pixel_data_ptr, size[0], size[1])))
         return RTAMD_ERR_INVALID;
     return RTAMD_OK;
 }
