@@ -70,6 +70,8 @@ def parse():
                          "reports the median repeat as ms_per_step / value and the extremes beside it")
     ap.add_argument("--workload", default=None, help="default: bunny_1080p (1 GPU) / field_4k (several GPUs)")
     ap.add_argument("--size", default=None, help="WxH: render the workload at another image size (experiments; the line names it)")
+    ap.add_argument("--soft-points", type=int, default=None, help="experiments: soft-shadow samples per light instead of the workload's (the line names it)")
+    ap.add_argument("--max-reflections", type=int, default=None, help="experiments: bounce depth instead of the workload's (the line names it)")
     ap.add_argument("--row-tile", type=int, default=16)
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH: faces per leaf (0 = library default)")
     ap.add_argument("--sah-bins", type=int, default=0, help="BVH: SAH bins (0 = library default)")
@@ -246,6 +248,14 @@ def main():
         w = dict(w)
         w["width"], w["height"] = (int(x) for x in a.size.lower().split("x"))
         name = "%s@%s" % (name, a.size.lower())
+    if a.soft_points is not None or a.max_reflections is not None:
+        w = dict(w)
+        if a.soft_points is not None:
+            w["soft_points"] = a.soft_points
+            name += "@soft%d" % a.soft_points
+        if a.max_reflections is not None:
+            w["max_reflections"] = a.max_reflections
+            name += "@depth%d" % a.max_reflections
     t0 = time.time()
     fly, params, cam = workloads.make_flyscene(w, max_leaf_faces=a.max_leaf, sah_bins=a.sah_bins, shadow_rays=a.shadow_rays, primary_rays=a.primary_rays, builder=a.builder)
     info = fly.info()

@@ -63,6 +63,10 @@ struct TimedLaunch {
 };
 
 constexpr int kMaxFrameSlots = 16;
+// Page-locked report block of a frame slot: [0..3] what the screen binning found, [kStageFeedbackAt + 2 * stage + {0, 1}]
+// hits and spawned rays of every stage, each + 1 (0: not reported yet).
+constexpr int kStageFeedbackAt = 16;
+constexpr int kFeedbackInts = kStageFeedbackAt + 2 * kMaxStages;
 
 // What one frame in flight owns.
 struct FrameSlot {
@@ -78,6 +82,7 @@ struct FrameSlot {
     // while it says that the lists were too long, the next frames of the same view walk the tree right away.
     volatile int32_t *feedback = nullptr;
     uint64_t feedback_key = 0;    // image size and partition the report belongs to
+    uint64_t view_key = 0;        // ... and the camera and pass structure the stage counts belong to
     int frames_without_bins = 0;
     std::vector<hipEvent_t> sync; // events that order the streams of a frame with reflections
 };
@@ -186,12 +191,13 @@ int ensure_workspace(rtamd_scene *s, FrameSlot &fs, size_t slots, size_t bins_ne
     const size_t nshadow = (size_t)s->ds.num_lights * (size_t)s->ds.spl;
     const size_t ntris = (size_t)s->info.num_device_faces;
     const size_t bins = s->bin_primary ? bins_needed : 0; // sized for the whole image this workspace may see
-    int32_t *const feedback = fs.ws.bin_feedback;
+    int32_t *const feedback = fs.ws.bin_feedback, *const stage_feedback = fs.ws.stage_feedback;
     Workspace sizes{};
     const size_t total = layout_workspace(nullptr, slots, nshadow, bins, ntris, sizes);
     HIP_TRY(hipMalloc(&fs.block, total));
     layout_workspace((char *)fs.block, slots, nshadow, bins, ntris, fs.ws);
     fs.ws.bin_feedback = feedback;
+    fs.ws.stage_feedback = stage_feedback;
     fs.bins = bins;
     return RTAMD_OK;
 }
@@ -243,11 +249,12 @@ int acquire_slot(rtamd_scene *s, hipStream_t stream, FrameSlot **out) {
         pick = s->num_slots++;
         HIP_TRY(hipEventCreateWithFlags(&s->slots[pick].done, hipEventDisableTiming));
         void *host = nullptr, *mapped = nullptr;
-        HIP_TRY(hipHostMalloc(&host, 64, hipHostMallocMapped));
-        std::memset(host, 0, 64);
+        HIP_TRY(hipHostMalloc(&host, kFeedbackInts * sizeof(int32_t), hipHostMallocMapped));
+        std::memset(host, 0, kFeedbackInts * sizeof(int32_t));
         HIP_TRY(hipHostGetDevicePointer(&mapped, host, 0));
         s->slots[pick].feedback = (volatile int32_t *)host;
         s->slots[pick].ws.bin_feedback = (int32_t *)mapped;
+        s->slots[pick].ws.stage_feedback = (int32_t *)mapped + kStageFeedbackAt;
         // the first slot's frames may use the side streams: let them end before a second caller stream joins
         if (pick == 1 && s->slots[0].used) HIP_TRY(hipEventSynchronize(s->slots[0].done));
     }
@@ -680,11 +687,33 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
     bool bins_kept_before = false;
     bool bins_ok = s->bin_primary && fs.ws.bin_entries != nullptr && bins_x < 32768 && bins_y < 32768 &&
                    (s->bin_always || (double)s->info.num_device_faces <= faces_per_pixel_max * (double)pixels);
+    // What earlier frames on this slot reported (page-locked memory their kernels wrote; a frame still in flight may be
+    // half-way through updating it, which is harmless: the figures only pick launch sizes and the cheaper of two
+    // equivalent paths).  Stage counts carry over between frames of one image size, partition and pass structure; the
+    // verdict on the screen bins only between frames of one view, camera included.
+    auto mix = [](uint64_t h, const void *data, size_t bytes) {
+        const unsigned char *b = (const unsigned char *)data;
+        for (size_t i = 0; i < bytes; ++i) h = (h ^ b[i]) * 1099511628211ull; // FNV-1a
+        return h;
+    };
+    const int32_t shape_words[8] = {p->width, p->height, p->part, p->num_parts, p->row_tile, S, depths, (int32_t)nshadow};
+    const uint64_t size_key = mix(14695981039346656037ull, shape_words, sizeof shape_words) | 1ull;
+    const uint64_t view_key = mix(size_key, cam, sizeof *cam) | 1ull;
+    std::vector<int> expect_hits((size_t)stages, -1), expect_next((size_t)stages, -1);
+    if (fs.feedback) {
+        if (fs.feedback_key != size_key) {
+            fs.feedback_key = size_key;
+            for (int i = kStageFeedbackAt; i < kFeedbackInts; ++i) fs.feedback[i] = 0;
+        }
+        static const bool sized = !getenv("RTAMD_WORST_CASE_LAUNCHES"); // experiment hook
+        for (int i = 0; sized && i < stages; ++i) {
+            expect_hits[(size_t)i] = fs.feedback[kStageFeedbackAt + 2 * i] - 1;
+            expect_next[(size_t)i] = fs.feedback[kStageFeedbackAt + 2 * i + 1] - 1;
+        }
+    }
     if (bins_ok && fs.feedback && !s->bin_always) {
-        const uint64_t key = (uint64_t)(uint32_t)p->width | ((uint64_t)(uint32_t)p->height << 20) | ((uint64_t)(uint32_t)p->part << 40) |
-                             ((uint64_t)(uint32_t)p->num_parts << 48) | ((uint64_t)(uint32_t)p->row_tile << 56);
-        if (fs.feedback_key != key) { // another view: what earlier passes reported says nothing about it
-            fs.feedback_key = key;
+        if (fs.view_key != view_key) { // another view: what earlier passes reported says nothing about it
+            fs.view_key = view_key;
             fs.feedback[0] = fs.feedback[1] = fs.feedback[2] = fs.feedback[3] = 0;
             fs.frames_without_bins = 0;
         }
@@ -801,11 +830,11 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
                 stream_of_launch = geo;
                 if ((rc = begin(d == 0 && bins_ok ? 6 : 0)) != RTAMD_OK) return rc;
                 if (d == 0 && bins_ok) launch_primary_bins(count, s->ds, fc, ws_frame, s->info.num_device_faces, /*cleared=*/stage == 0, geo);
-                launch_walk_closest(d == 0, count, s->ds, fc, ws_frame, stage, d, geo); // after the bins: only on their overflow
+                launch_walk_closest(d == 0, count, s->ds, fc, ws_frame, stage, d, d > 0 ? expect_next[(size_t)stage - 1] : -1, geo); // after the bins: only on their overflow
                 if ((rc = end()) != RTAMD_OK) return rc;
                 if (two_streams && d >= 2) HIP_TRY(hipStreamWaitEvent(geo, shaded(d - 2), 0));
                 if ((rc = begin(2)) != RTAMD_OK) return rc;
-                launch_compact(d == 0, s->ds, fc, fs.ws, stage, d, spawn, deep_bg && d > 0, rgb, face_id, t_hit, geo);
+                launch_compact(d == 0, s->ds, fc, fs.ws, stage, d, spawn, deep_bg && d > 0, rgb, face_id, t_hit, d > 0 ? expect_next[(size_t)stage - 1] : -1, geo);
                 if ((rc = end()) != RTAMD_OK) return rc;
                 if (two_streams) HIP_TRY(hipEventRecord(compacted(d), geo));
                 // ---- shadow rays: depth 0 on the caller's stream, deeper ones beside it
@@ -814,7 +843,7 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
                 if (nshadow > 0) {
                     stream_of_launch = sh;
                     if ((rc = begin(1)) != RTAMD_OK) return rc;
-                    launch_walk_shadow(count, s->ds, fc, fs.ws, stage, d, sh);
+                    launch_walk_shadow(count, s->ds, fc, fs.ws, stage, d, expect_hits[(size_t)stage], sh);
                     if ((rc = end()) != RTAMD_OK) return rc;
                 }
                 if (two_streams && d > 0) {
@@ -824,8 +853,8 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
                 // ---- shading, in depth order
                 stream_of_launch = stream;
                 if ((rc = begin(3)) != RTAMD_OK) return rc;
-                launch_shade(d == 0, s->ds, fc, fs.ws, stage, d, spawn, rgb, stream);
-                if (deep_bg && d > 0) launch_misses(fc, fs.ws, stage, d, rgb, stream);
+                launch_shade(d == 0, s->ds, fc, fs.ws, stage, d, spawn, rgb, expect_hits[(size_t)stage], stream);
+                if (deep_bg && d > 0) launch_misses(fc, fs.ws, stage, d, rgb, expect_next[(size_t)stage - 1], stream);
                 if ((rc = end()) != RTAMD_OK) return rc;
                 if (two_streams) HIP_TRY(hipEventRecord(shaded(d), stream));
             }

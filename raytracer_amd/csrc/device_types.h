@@ -117,6 +117,9 @@ struct Workspace {
     // host memory the pass reports its BinState to (total, nonempty, fallback, 1), so that the host can leave the
     // binning out of the NEXT frames of a view whose lists are too long; never read by the device
     int32_t *bin_feedback;
+    // ... and where every stage reports its hit and ray counts (+ 1; two ints per stage), for the sizes of later
+    // frames' launches; nullptr: no report
+    int32_t *stage_feedback;
     // Frames overlap on the GPU (the scene is rendered on several streams): small bounce launches keep full waves of
     // one ray per lane, which is the least work, instead of spreading the rays over more, narrower waves, which is
     // the shortest chain for a launch alone on the chip.  Same results either way.

@@ -13,14 +13,17 @@ namespace rtamd {
 // Screen binning of the primary rays of one pass (ws.bin_entries must be set): count, claim, fill, test.
 void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, bool cleared,
                          hipStream_t stream);
+// `expect` (launches whose size is only known on the device): the count an earlier frame of the view reported for this
+// point of the frame -- bounce rays of the stage, or its hits -- or -1: cover the worst case.
 void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth,
-                         hipStream_t stream);
+                         int expect, hipStream_t stream);
 void launch_compact(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, bool spawn,
-                    bool list_misses, float *rgb, int32_t *face_id, float *t_hit, hipStream_t stream);
-void launch_walk_shadow(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, hipStream_t stream);
+                    bool list_misses, float *rgb, int32_t *face_id, float *t_hit, int expect, hipStream_t stream);
+void launch_walk_shadow(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, int expect,
+                        hipStream_t stream);
 void launch_shade(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, bool spawn, float *rgb,
-                  hipStream_t stream);
-void launch_misses(const FrameConst &fc, const Workspace &ws, int stage, int depth, float *rgb, hipStream_t stream);
+                  int expect, hipStream_t stream);
+void launch_misses(const FrameConst &fc, const Workspace &ws, int stage, int depth, float *rgb, int expect, hipStream_t stream);
 void launch_scale(float *rgb, size_t n, float divisor, hipStream_t stream);
 void launch_quantize(const float *rgb, uint8_t *out, size_t n, hipStream_t stream);
 void launch_assemble(const void *src, void *dst, int width, int height, int channels, int row_tile, int num_parts, hipStream_t stream);

@@ -35,6 +35,7 @@
 // the reference accepts it and then returns a visiting-order-dependent face.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdint>
 #include <cstdlib>
@@ -975,6 +976,122 @@ __global__ __launch_bounds__(64) void shadow_grid_kernel(DeviceScene sc, FrameCo
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same shadow rays with the lanes of a wave kept busy.  In shadow_grid_kernel a wave lasts as long as the longest
+// candidate list among its 64 rays while the average ray is done after one or two batches: a third of the lanes work.
+// Here a wave owns a run of `chunk` consecutive hits of one sample and hands them to its lanes as they fall idle: a
+// lane that has settled its ray (occluder found, rest of the list behind the origin, list exhausted) takes the next
+// hit of the run in the same loop iteration, so the wave runs for about (sum of the lists) / 64 iterations plus the
+// tail of its last rays instead of (longest list) per 64 rays.  The order in which rays are settled does not matter:
+// every ray writes its own byte.  Runs stay sample-major, so the waves in flight still work on one grid at a time.
+// ---------------------------------------------------------------------------------------------
+#ifndef RT_SHADOW_POOL_WAVES
+#define RT_SHADOW_POOL_WAVES 16384
+#endif
+template <bool COUNT>
+__global__ __launch_bounds__(64) void shadow_pool_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth) {
+    const int lane = (int)threadIdx.x;
+    const int nshadow = sc.num_lights * sc.spl;
+    const int nhits = ws.stage[stage].hits;
+    if (nhits <= 0) return;
+    // hits per wave: long runs amortise the tail, but the launch must still spread over the chip
+    const long long rays = (long long)nhits * nshadow;
+    int chunk = 64;
+    while (chunk < 512 && rays / (chunk * 2) >= RT_SHADOW_POOL_WAVES) chunk *= 2;
+    const int chunks = (nhits + chunk - 1) / chunk;
+    const int ngroups = chunks * nshadow;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const float *hp = ws.hits[depth & 1].p;
+    unsigned w_box = 0, w_plane = 0, w_edge = 0;
+    for (int group = (int)blockIdx.x; group < ngroups; group += (int)gridDim.x) {
+        const int sample = group / chunks, run = group - sample * chunks;
+        int next = run * chunk;
+        const int last = min(next + chunk, nhits);
+        const float4 g0 = sc.grid_headers[sample * 4 + 0], g1 = sc.grid_headers[sample * 4 + 1];
+        const float4 g2 = sc.grid_headers[sample * 4 + 2], g3 = sc.grid_headers[sample * 4 + 3];
+        const int res = __float_as_int(g3.x), first_cell = __float_as_int(g3.y);
+        const V3 d = mk(sc.samples[3 * sample], sc.samples[3 * sample + 1], sc.samples[3 * sample + 2]);
+        uint8_t *const out = ws.clear[depth & 1] + (size_t)sample * (size_t)ws.capacity;
+        int hit = -1, e = 0, end = 0;
+        float z = 0.0f;
+        V3 o = mk(0, 0, 0);
+        for (;;) {
+            // ---- idle lanes take the next hits of the run
+            const bool idle = hit < 0;
+            const unsigned long long want = __ballot(idle);
+            if (want != 0ull && next < last) {
+                const int cand = next + (int)__popcll(want & below);
+                next += (int)__popcll(want);
+                if (idle && cand < last) {
+                    hit = cand;
+                    o = mk(hp[hit], hp[(size_t)ws.capacity + hit], hp[2 * (size_t)ws.capacity + hit]);
+                    e = end = 0;
+                    float tsphere = FLT_MAX;
+                    if (sc.num_spheres > 0 && spheres_hit(sc, o, d, fc.t_eps, tsphere)) { // intersects(): spheres first (:673-676)
+                        out[hit] = 0;
+                        hit = -1;
+                    } else {
+                        // header: U (g0.xyz), V (g0.w g1.xy), W (g1.zw g2.x), u0 v0 inv_cell (g2.yzw), res first_cell (g3.xy)
+                        const float u = o.x * g0.x + (o.y * g0.y + o.z * g0.z);
+                        const float v = o.x * g0.w + (o.y * g1.x + o.z * g1.y);
+                        z = o.x * g1.z + (o.y * g1.w + o.z * g2.x);
+                        const float fx = floorf((u - g2.y) * g2.w), fy = floorf((v - g2.z) * g2.w);
+                        if (COUNT) ++w_box;
+                        if (fx >= 0.0f && fy >= 0.0f && fx < (float)res && fy < (float)res) {
+                            const int cell = first_cell + (int)fy * res + (int)fx;
+                            e = sc.grid_cells[cell], end = sc.grid_cells[cell + 1];
+                        }
+                    }
+                }
+            }
+            const bool active = hit >= 0;
+            if (__ballot(active) == 0ull) {
+                if (next >= last) break;
+                continue;
+            }
+            // ---- one batch of candidates for every lane that holds a ray
+            bool blocked = false, behind = false;
+            if (active && e < end) {
+                int2 ent[RT_SHADOW_BATCH];
+#pragma unroll
+                for (int k = 0; k < RT_SHADOW_BATCH; ++k) ent[k] = sc.grid_entries[min(e + k, end - 1)];
+                float4 pn[RT_SHADOW_BATCH];
+#pragma unroll
+                for (int k = 0; k < RT_SHADOW_BATCH; ++k) pn[k] = sc.tris[ent[k].x * 4 + 0];
+#pragma unroll
+                for (int k = 0; k < RT_SHADOW_BATCH; ++k) {
+                    if (blocked || behind || e + k >= end) continue;
+                    if (__int_as_float(ent[k].y) < z) { // this face and all later ones lie behind the origin
+                        behind = true;
+                        continue;
+                    }
+                    const int i = ent[k].x;
+                    if (COUNT) ++w_plane;
+                    const V3 n = mk(pn[k].x, pn[k].y, pn[k].z);
+                    const float t = (pn[k].w - dot(o, n)) / dot(d, n);
+                    if (!(t >= fc.t_eps && t <= FLT_MAX)) continue; // also rejects NaN (see file header)
+                    const float4 p0 = sc.tris[i * 4 + 1];
+                    const float4 p1 = sc.tris[i * 4 + 2];
+                    const float4 p2 = sc.tris[i * 4 + 3];
+                    if (COUNT) ++w_edge;
+                    const V3 v0 = mk(p0.x, p0.y, p0.z), v1 = mk(p1.x, p1.y, p1.z), v2 = mk(p2.x, p2.y, p2.z);
+                    const V3 at = o + t * d;
+                    if (dot(cross(v1 - v0, at - v0), n) < 0) continue;
+                    if (dot(cross(v2 - v1, at - v1), n) < 0) continue;
+                    if (dot(cross(v0 - v2, at - v2), n) < 0) continue;
+                    blocked = true;
+                }
+                e += RT_SHADOW_BATCH;
+            }
+            if (active && (blocked || behind || e >= end)) { // settled: the sample reaches the point unless a face blocks it
+                out[hit] = blocked ? 0 : 1;
+                hit = -1;
+            }
+        }
+    }
+    if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 1);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Compaction: ray slots that hit something -> dense hit list (slot order inside a workgroup, one atomic
 // per workgroup and list: atomics on one address serialise in L2, so a workgroup covers up to 2048 slots).  Also writes the hit point, the primary planes (face id, distance), the colour
 // of primary rays that hit nothing (src/flyscene.cpp:650-658), and -- the reflection set-up of traceRay,
@@ -989,10 +1106,10 @@ __global__ __launch_bounds__(256) void compact_kernel(DeviceScene sc, FrameConst
     __shared__ int s_count[3][kCompactSegments][4]; // list (hits, spawned rays, misses) x segment x wave
     __shared__ int s_base[3];
     const int total = PRIMARY ? total_static : ws.stage[stage - 1].next;
-    const int first = (int)blockIdx.x * (256 * kCompactSegments);
-    if (first >= total) return;
     const HitList hl = ws.hits[depth & 1];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the grid may be smaller than the work (it is sized from what earlier frames of the view needed): stride over it
+    for (int first = (int)blockIdx.x * (256 * kCompactSegments); first < total; first += (int)gridDim.x * (256 * kCompactSegments)) {
 
     // ---- pass 1: classify the slots of every segment, count per wave
     int tri_of[kCompactSegments];
@@ -1100,19 +1217,22 @@ __global__ __launch_bounds__(256) void compact_kernel(DeviceScene sc, FrameConst
         }
         if (miss) hl.slot[ws.capacity - 1 - pos_miss] = slot; // hits + misses <= rays <= capacity: the two ends never meet
     }
+    __syncthreads(); // the counts in LDS are reused by the next run
+    }
 }
 
 // A bounce ray that hits nothing adds throughput * background_deep (zero in the reference,
 // src/flyscene.cpp:661-665, so this kernel only runs when a caller sets that colour).
 __global__ __launch_bounds__(256) void miss_kernel(FrameConst fc, Workspace ws, int stage, int depth, float *rgb) {
-    const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (idx >= ws.stage[stage].misses) return;
-    const int slot = ws.hits[depth & 1].slot[ws.capacity - 1 - idx];
-    const float *q = ws.queue[depth % 3];
-    float *p = rgb + 3 * (size_t)__float_as_int(plane(q, ws.capacity, 9)[slot]);
-    p[0] += plane(q, ws.capacity, 6)[slot] * fc.bg_deep[0];
-    p[1] += plane(q, ws.capacity, 7)[slot] * fc.bg_deep[1];
-    p[2] += plane(q, ws.capacity, 8)[slot] * fc.bg_deep[2];
+    const int misses = ws.stage[stage].misses;
+    for (int idx = (int)(blockIdx.x * 256 + threadIdx.x); idx < misses; idx += (int)gridDim.x * 256) {
+        const int slot = ws.hits[depth & 1].slot[ws.capacity - 1 - idx];
+        const float *q = ws.queue[depth % 3];
+        float *p = rgb + 3 * (size_t)__float_as_int(plane(q, ws.capacity, 9)[slot]);
+        p[0] += plane(q, ws.capacity, 6)[slot] * fc.bg_deep[0];
+        p[1] += plane(q, ws.capacity, 7)[slot] * fc.bg_deep[1];
+        p[2] += plane(q, ws.capacity, 8)[slot] * fc.bg_deep[2];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1121,9 +1241,14 @@ __global__ __launch_bounds__(256) void miss_kernel(FrameConst fc, Workspace ws, 
 template <bool PRIMARY>
 __global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth, int spawn, float *rgb) {
     const int nhits = ws.stage[stage].hits;
-    const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (idx >= nhits) return;
+    // Report what this stage held to the host (page-locked memory, never read by the device): the next frames of the
+    // view size their launches from it instead of from the worst case.  Stored + 1: zero means "nothing reported yet".
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ws.stage_feedback) {
+        ws.stage_feedback[2 * stage] = nhits + 1;
+        ws.stage_feedback[2 * stage + 1] = ws.stage[stage].next + 1;
+    }
     const HitList hl = ws.hits[depth & 1];
+    for (int idx = (int)(blockIdx.x * 256 + threadIdx.x); idx < nhits; idx += (int)gridDim.x * 256) {
 
     const V3 P = mk(plane(hl.p, ws.capacity, 0)[idx], plane(hl.p, ws.capacity, 1)[idx], plane(hl.p, ws.capacity, 2)[idx]);
     // getLightIntensity, src/flyscene.cpp:870-896: share of unoccluded samples per light, summed, capped at 1
@@ -1187,9 +1312,9 @@ __global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, FrameConst f
                 const float u = (a12 * s5.z + a02 * s6.x) + a01 * s6.z;
                 const float v = (a12 * s5.w + a02 * s6.y) + a01 * s6.w;
                 const int first = sc.tex_info[4 * tex], w = sc.tex_info[4 * tex + 1], h = sc.tex_info[4 * tex + 2];
-                const double idx = (double)floorf(v * (float)h) * (double)w + (double)floorf(u * (float)w);
+                const double texel = (double)floorf(v * (float)h) * (double)w + (double)floorf(u * (float)w);
                 const double last = (double)w * (double)h - 1.0;
-                const int at = !(idx >= 0.0) ? 0 : idx > last ? (int)last : (int)idx;
+                const int at = !(texel >= 0.0) ? 0 : texel > last ? (int)last : (int)texel;
                 const float *tx = sc.texels + 3 * (size_t)(first + at);
                 albedo = mk(tx[0], tx[1], tx[2]);
             }
@@ -1227,6 +1352,7 @@ __global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, FrameConst f
             float *q = ws.queue[(depth + 1) % 3];
             plane(q, ws.capacity, 6)[child] = nT.x, plane(q, ws.capacity, 7)[child] = nT.y, plane(q, ws.capacity, 8)[child] = nT.z;
         }
+    }
     }
 }
 
@@ -1330,13 +1456,24 @@ void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc
         raster_kernel<false><<<(total_static + 255) / 256, 256, 0, stream>>>(sc, fc, ws, total_static);
 }
 
+// `expect`: what an earlier frame of the same view held at this point (rays of a bounce stage, hits of a stage), or
+// -1 when nothing is known.  Launches whose size is only known on the device cover the worst case then; with a figure
+// they are cut to it plus a quarter.  Every kernel sized this way strides over its work, so a figure that turns out
+// too small costs time, never results.
+namespace {
+long long with_margin(int expect) { return (long long)expect + (expect >> 2) + 64; }
+} // namespace
+
 void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth,
-                         hipStream_t stream) {
+                         int expect, hipStream_t stream) {
     const int total_static = fc.tiles_x * fc.tiles_y * 64;
     // bounce queues are at most as long as the slot count: that is the worst case the grid covers
     // With screen binning in use the primary walk only runs when the pass turned its bins down (overflow, or
     // lists too long to pay): a moderate grid (the kernel strides over the groups) keeps the usual early exit cheap.
-    const int blocks = primary && ws.bin_entries ? (ws.bins_expected ? 2048 : 16384) : walk_grid(primary ? fc.tiles_x * fc.tiles_y : ws.capacity / 64);
+    long long groups = primary ? fc.tiles_x * fc.tiles_y : ws.capacity / 64;
+    if (!primary && expect >= 0) // narrow groups (a launch alone on the chip) hold as few as sixteen rays
+        groups = std::min(groups, (with_margin(expect) + (ws.full_waves ? 63 : 15)) / (ws.full_waves ? 64 : 16));
+    const int blocks = primary && ws.bin_entries ? (ws.bins_expected ? 2048 : 16384) : walk_grid(groups);
     if (primary) {
         if (count)
             walk_kernel<kPrimary, true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, total_static);
@@ -1351,12 +1488,13 @@ void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const 
 }
 
 void launch_compact(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, bool spawn,
-                    bool list_misses, float *rgb, int32_t *face_id, float *t_hit, hipStream_t stream) {
+                    bool list_misses, float *rgb, int32_t *face_id, float *t_hit, int expect, hipStream_t stream) {
     const int total_static = fc.tiles_x * fc.tiles_y * 64;
-    const int slots = primary ? total_static : ws.capacity;
+    long long slots = primary ? total_static : ws.capacity;
+    if (!primary && expect >= 0) slots = std::min(slots, with_margin(expect));
     const bool large = slots > (4 << 20);
     const int per_block = 256 * (large ? 8 : 2);
-    const int blocks = (slots + per_block - 1) / per_block;
+    const int blocks = (int)((slots + per_block - 1) / per_block);
     if (primary) {
         if (large)
             compact_kernel<true, 8><<<blocks, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, 0, rgb, face_id, t_hit, total_static);
@@ -1370,11 +1508,26 @@ void launch_compact(bool primary, const DeviceScene &sc, const FrameConst &fc, c
     }
 }
 
-void launch_walk_shadow(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, hipStream_t stream) {
+void launch_walk_shadow(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, int expect,
+                        hipStream_t stream) {
     const int nshadow = sc.num_lights * sc.spl;
     if (nshadow <= 0) return;
-    const int blocks = walk_grid((long long)(fc.tiles_x * fc.tiles_y) * nshadow);
+    long long groups = (long long)(fc.tiles_x * fc.tiles_y) * nshadow;
+    if (expect >= 0) { // small launches put sixteen lanes on a ray: four hits per group
+        const long long hits = with_margin(expect);
+        const bool split = sc.use_grids && hits * nshadow < RT_SHADOW_SPLIT_BELOW;
+        groups = std::min(groups, (split ? (hits + 3) / 4 : (hits + 63) / 64) * nshadow);
+    }
+    const int blocks = walk_grid(groups);
     if (sc.use_grids) {
+        static const int pool = getenv("RTAMD_SHADOW_POOL") ? atoi(getenv("RTAMD_SHADOW_POOL")) : 0; // experiment hook
+        if (pool) {
+            if (count)
+                shadow_pool_kernel<true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth);
+            else
+                shadow_pool_kernel<false><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth);
+            return;
+        }
         if (count)
             shadow_grid_kernel<true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth);
         else
@@ -1388,16 +1541,20 @@ void launch_walk_shadow(bool count, const DeviceScene &sc, const FrameConst &fc,
 }
 
 void launch_shade(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, bool spawn, float *rgb,
-                  hipStream_t stream) {
-    const int sblocks = (ws.capacity + 255) / 256;
+                  int expect, hipStream_t stream) {
+    long long hits = ws.capacity;
+    if (expect >= 0) hits = std::min(hits, with_margin(expect));
+    const int sblocks = (int)((hits + 255) / 256);
     if (primary)
         shade_kernel<true><<<sblocks, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, rgb);
     else
         shade_kernel<false><<<sblocks, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, rgb);
 }
 
-void launch_misses(const FrameConst &fc, const Workspace &ws, int stage, int depth, float *rgb, hipStream_t stream) {
-    miss_kernel<<<(ws.capacity + 255) / 256, 256, 0, stream>>>(fc, ws, stage, depth, rgb);
+void launch_misses(const FrameConst &fc, const Workspace &ws, int stage, int depth, float *rgb, int expect, hipStream_t stream) {
+    long long rays = ws.capacity;
+    if (expect >= 0) rays = std::min(rays, with_margin(expect));
+    miss_kernel<<<(unsigned)((rays + 255) / 256), 256, 0, stream>>>(fc, ws, stage, depth, rgb);
 }
 
 void launch_scale(float *rgb, size_t n, float divisor, hipStream_t stream) {
