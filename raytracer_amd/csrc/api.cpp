@@ -161,6 +161,10 @@ size_t layout_workspace(char *base, size_t slots, size_t nshadow, size_t bins, s
         ws.bin_count = (int32_t *)take((bins + 256) * 4);
         align(1024);
     }
+    // tiles_x * 8 + tiles_y * 8 <= slots / 8 + 8 whatever the image's shape
+    ws.dir_x = (float *)take((cap / 8 + 64) * 4);
+    ws.dir_y = ws.dir_x; // placed per frame, behind the columns (enqueue_frame)
+    align(1024);
     ws.slot_tri = (int32_t *)take(cap * 4);
     ws.slot_t = (float *)take(cap * 4);
     for (HitList &h : ws.hits) {
@@ -675,6 +679,8 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
     fc.width = p->width, fc.height = p->height, fc.local_rows = local_rows;
     fc.tiles_x = tiles_x, fc.tiles_y = tiles_y;
     fc.row_tile = p->row_tile, fc.num_parts = p->num_parts, fc.part = p->part;
+    fc.tiles_x_magic = tiles_x == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint64_t)tiles_x);
+    fc.row_tile_magic = p->row_tile == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint64_t)p->row_tile);
     fc.t_eps = p->t_epsilon, fc.refl_thresh = p->reflect_threshold, fc.bounce_off = p->bounce_offset;
     std::memcpy(fc.bg, p->background, sizeof fc.bg);
     std::memcpy(fc.bg_deep, p->background_deep, sizeof fc.bg_deep);
@@ -745,6 +751,7 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
         }
         fc.bins_x = bins_x, fc.bins_y = bins_y;
     }
+    fs.ws.dir_y = fs.ws.dir_x + tiles_x * 8;
     Workspace ws_frame = fs.ws; // what the kernels of this frame see
     if (!bins_ok) ws_frame.bin_entries = nullptr;
     fs.binned = bins_ok;
@@ -812,24 +819,29 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
     auto shadowed = [&](int d) { return fs.sync[(size_t)(3 + 3 * d)]; };
     const bool deep_bg = p->background_deep[0] != 0.0f || p->background_deep[1] != 0.0f || p->background_deep[2] != 0.0f;
 
-    // stage and work counters, and with them the bin counters of the first pass (they lie right behind)
-    HIP_TRY(hipMemsetAsync(fs.block, 0, 4096 + (bins_ok ? 256 + sizeof(int32_t) * (size_t)ws_frame.num_bins : 0), stream));
+    // Every pass starts with prep_kernel: it fills the pass's screen-coordinate tables and zeroes the bin counters; the first
+    // one also zeroes the stage and work counters of the frame, which lie right in front of them.
+    const size_t bin_clear = bins_ok ? ((256 + sizeof(int32_t) * (size_t)ws_frame.num_bins + 15) & ~(size_t)15) : 0;
     int stage = 0;
     for (int xs = 0; xs < S; ++xs)
         for (int ys = 0; ys < S; ++ys) {
             fc.sub_x = (float)xs / S; // src/flyscene.cpp:816-817
             fc.sub_y = (float)ys / S;
             fc.accumulate = (xs | ys) != 0;
-            if (two_streams) { // everything enqueued so far (counters cleared, previous pass shaded) precedes this pass
+            if (two_streams) { // everything enqueued so far (previous frame, previous pass shaded) precedes this pass
                 HIP_TRY(hipEventRecord(fs.sync[0], stream));
                 HIP_TRY(hipStreamWaitEvent(geo, fs.sync[0], 0));
             }
+            if (stage == 0)
+                launch_prep(fc, ws_frame, fs.block, 4096 + bin_clear, geo);
+            else
+                launch_prep(fc, ws_frame, (char *)fs.block + 4096, bin_clear, geo);
             for (int d = 0; d < depths; ++d, ++stage) {
                 const bool spawn = d + 1 < depths;
                 // ---- closest hits
                 stream_of_launch = geo;
                 if ((rc = begin(d == 0 && bins_ok ? 6 : 0)) != RTAMD_OK) return rc;
-                if (d == 0 && bins_ok) launch_primary_bins(count, s->ds, fc, ws_frame, s->info.num_device_faces, /*cleared=*/stage == 0, geo);
+                if (d == 0 && bins_ok) launch_primary_bins(count, s->ds, fc, ws_frame, s->info.num_device_faces, /*cleared=*/true, geo);
                 launch_walk_closest(d == 0, count, s->ds, fc, ws_frame, stage, d, d > 0 ? expect_next[(size_t)stage - 1] : -1, geo); // after the bins: only on their overflow
                 if ((rc = end()) != RTAMD_OK) return rc;
                 if (two_streams && d >= 2) HIP_TRY(hipStreamWaitEvent(geo, shaded(d - 2), 0));

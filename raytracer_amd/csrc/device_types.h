@@ -43,6 +43,7 @@ struct FrameConst {
     int32_t width, height, local_rows;
     int32_t tiles_x, tiles_y; // 8x8-pixel tiles of the local image
     int32_t row_tile, num_parts, part;
+    uint32_t tiles_x_magic, row_tile_magic; // floor(2^32 / tiles_x), floor(2^32 / row_tile) (0xffffffff for 1): fast_div in kernels.hip
     float t_eps, refl_thresh, bounce_off;
     float bg[3], bg_deep[3];
     int32_t accumulate; // 0: first SSAA pass stores the pixel, 1: later passes add to it
@@ -103,6 +104,8 @@ struct Workspace {
     // Geometry and pixel are written when the ray is spawned (compaction kernel of the parent depth), the
     // throughput later by the shading kernel of the parent depth.
     float *queue[3];
+    // screen coordinates of the current pass's primary rays (prep_kernel): per image column, per local row
+    float *dir_x, *dir_y;
     StageCounters *stage; // kMaxStages
     WorkCounters *work;   // [0] closest-hit walk, [1] shadow kernel, [2] screen-bin raster
     // screen binning of the primary rays; bin_entries == nullptr: not in use

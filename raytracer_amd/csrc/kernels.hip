@@ -87,21 +87,29 @@ __device__ __forceinline__ const float *plane(const float *base, int capacity, i
 // Camera ray of one pixel sample: Camera::screenToWorld (camera.hpp:158-176, double intermediates
 // kept) followed by (p - origin).normalized() (src/flyscene.cpp:822).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ V3 camera_direction(const FrameConst &fc, float px, float py) {
+__device__ __forceinline__ float screen_x(const FrameConst &fc, float px) {
     float nx = (float)(2.0 * (double)(px - fc.vp[0]) / (double)fc.vp[2] - 1.0);
-    float ny = (float)(1.0 - 2.0 * (double)(py - fc.vp[1]) / (double)fc.vp[3]);
-    const float nz = -1.0f;
     nx *= fc.ax;
+    return nx;
+}
+__device__ __forceinline__ float screen_y(const FrameConst &fc, float py) {
+    float ny = (float)(1.0 - 2.0 * (double)(py - fc.vp[1]) / (double)fc.vp[3]);
     ny *= fc.scale;
-    const float *m = fc.inv_view;
-    const V3 w = mk(m[3] + (m[0] * nx + m[1] * ny + m[2] * nz), m[7] + (m[4] * nx + m[5] * ny + m[6] * nz),
-                    m[11] + (m[8] * nx + m[9] * ny + m[10] * nz));
-    return normalized(w - mk(fc.origin[0], fc.origin[1], fc.origin[2]));
+    return ny;
+}
+
+// n / d for any 32-bit n with magic = floor(2^32 / d) (0xffffffff for d == 1): the high product is the quotient or one
+// below it, one correction settles it.  A division by a run-time value costs about thirty instructions otherwise.
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned d, unsigned magic) {
+    unsigned q = __umulhi(n, magic);
+    if (n - q * d >= d) ++q;
+    return q;
 }
 
 // Image row of a local (packed) row under the row-tile partition.
 __device__ __forceinline__ int global_row(const FrameConst &fc, int local_row) {
-    const int tile = local_row / fc.row_tile;
+    if (fc.num_parts == 1) return local_row;
+    const int tile = (int)fast_div((unsigned)local_row, (unsigned)fc.row_tile, fc.row_tile_magic);
     return (tile * fc.num_parts + fc.part) * fc.row_tile + (local_row - tile * fc.row_tile);
 }
 
@@ -109,14 +117,22 @@ __device__ __forceinline__ int global_row(const FrameConst &fc, int local_row) {
 // consecutive slots are a compact screen region.  Returns false for the padding of edge tiles.
 __device__ __forceinline__ bool slot_pixel(const FrameConst &fc, int slot, int &x, int &row) {
     const int tile = slot >> 6, in = slot & 63;
-    const int ty = tile / fc.tiles_x, tx = tile - ty * fc.tiles_x;
+    const int ty = (int)fast_div((unsigned)tile, (unsigned)fc.tiles_x, fc.tiles_x_magic), tx = tile - ty * fc.tiles_x;
     x = tx * 8 + (in & 7);
     row = ty * 8 + (in >> 3);
     return x < fc.width && row < fc.local_rows;
 }
 
-__device__ __forceinline__ V3 primary_direction(const FrameConst &fc, int x, int row) {
-    return camera_direction(fc, (float)x + fc.sub_x, (float)global_row(fc, row) + fc.sub_y);
+// Direction of the primary ray of pixel (x, local row): camera_direction with the two screen coordinates -- which
+// depend on the column alone and on the row alone -- read from the tables that prep_kernel filled for this pass
+// with camera_direction's own expressions (double-precision divisions once per column and row, not per pixel).
+__device__ __forceinline__ V3 primary_direction(const FrameConst &fc, const Workspace &ws, int x, int row) {
+    const float nx = ws.dir_x[x], ny = ws.dir_y[row];
+    const float nz = -1.0f;
+    const float *m = fc.inv_view;
+    const V3 w = mk(m[3] + (m[0] * nx + m[1] * ny + m[2] * nz), m[7] + (m[4] * nx + m[5] * ny + m[6] * nz),
+                    m[11] + (m[8] * nx + m[9] * ny + m[10] * nz));
+    return normalized(w - mk(fc.origin[0], fc.origin[1], fc.origin[2]));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -295,7 +311,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
             valid = slot_pixel(fc, item, x, row);
             out_index = item;
             o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
-            if (valid) d = primary_direction(fc, x, row);
+            if (valid) d = primary_direction(fc, ws, x, row);
         } else if (MODE == kQueue) {
             valid = valid && item < rays;
             out_index = item;
@@ -812,16 +828,19 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst 
             ws.slot_tri[slot] = -2; // padding of an edge tile
         } else {
             const int gy = global_row(fc, row);
-            const V3 o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
-            const V3 d = primary_direction(fc, x, row);
-            float tbest = FLT_MAX;
-            int best_tri = -2, best_rank = -1;
-            // intersects(): spheres first, then triangles, sharing the running maximum (:673-676)
-            if (sc.num_spheres > 0 && spheres_hit(sc, o, d, fc.t_eps, tbest)) best_tri = -1;
             const int bx = x / kBinPixels, by = gy / kBinPixels;
             const int bin = by * fc.bins_x + bx;
-            const int begin = ws.bin_start[bin], nlist = ws.bin_count[bin], nbig = ws.bin_state->num_big;
+            const int nlist = ws.bin_count[bin], nbig = ws.bin_state->num_big;
             if (COUNT) ++w_box;
+            float tbest = FLT_MAX;
+            int best_tri = -2, best_rank = -1;
+            // most pixels of most frames see no face at all: no candidates, no ray
+            if (nlist + nbig > 0 || sc.num_spheres > 0) {
+            const int begin = ws.bin_start[bin];
+            const V3 o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
+            const V3 d = primary_direction(fc, ws, x, row);
+            // intersects(): spheres first, then triangles, sharing the running maximum (:673-676)
+            if (sc.num_spheres > 0 && spheres_hit(sc, o, d, fc.t_eps, tbest)) best_tri = -1;
             // Candidates are taken a few at a time (RT_RASTER_BATCH): their index loads, then their plane loads, are
             // independent, so a long list costs that much fewer dependent-load round trips.  The order of the candidates does
             // not matter: equal distances are settled by the faces' ranks.
@@ -868,6 +887,7 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst 
                     best_tri = i;
                     best_rank = rank;
                 }
+            }
             }
             ws.slot_tri[slot] = best_tri;
             ws.slot_t[slot] = tbest;
@@ -1189,7 +1209,7 @@ __global__ __launch_bounds__(256) void compact_kernel(DeviceScene sc, FrameConst
                 }
             }
             o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
-            if (hit) d = primary_direction(fc, x, row);
+            if (hit) d = primary_direction(fc, ws, x, row);
         } else if (hit) {
             const float *q = ws.queue[depth % 3];
             o = mk(plane(q, ws.capacity, 0)[slot], plane(q, ws.capacity, 1)[slot], plane(q, ws.capacity, 2)[slot]);
@@ -1356,6 +1376,20 @@ __global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, FrameConst f
     }
 }
 
+// Start of a pass: zero the counters the pass counts up from (`zero16` 16-byte words from `zero`), and fill the
+// tables of the pass's screen coordinates (primary_direction): dir_x per image column, dir_y per LOCAL row.
+__global__ __launch_bounds__(256) void prep_kernel(FrameConst fc, Workspace ws, int4 *zero, int zero16) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    for (int k = i; k < zero16; k += (int)gridDim.x * 256) zero[k] = make_int4(0, 0, 0, 0);
+    const int nx = fc.tiles_x * 8, ny = fc.tiles_y * 8;
+    for (int k = i; k < nx + ny; k += (int)gridDim.x * 256) {
+        if (k < nx)
+            ws.dir_x[k] = screen_x(fc, (float)k + fc.sub_x);
+        else
+            ws.dir_y[k - nx] = screen_y(fc, (float)global_row(fc, k - nx) + fc.sub_y);
+    }
+}
+
 // pixel /= SSAALEVEL^2, src/flyscene.cpp:830
 __global__ void scale_kernel(float *rgb, size_t n, float divisor) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1425,6 +1459,13 @@ int walk_grid(long long groups) {
     return (int)(b < 8 ? 8 : b);
 }
 } // namespace
+
+void launch_prep(const FrameConst &fc, const Workspace &ws, void *zero, size_t zero_bytes, hipStream_t stream) {
+    const int zero16 = (int)((zero_bytes + 15) / 16);
+    const int items = std::max(zero16, (fc.tiles_x + fc.tiles_y) * 8);
+    const int blocks = std::max(1, std::min(1024, (items + 255) / 256));
+    prep_kernel<<<blocks, 256, 0, stream>>>(fc, ws, (int4 *)zero, zero16);
+}
 
 void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, bool cleared,
                          hipStream_t stream) {
