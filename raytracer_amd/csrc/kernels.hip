@@ -537,6 +537,287 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
 }
 
 // ---------------------------------------------------------------------------------------------
+// Closest-hit walk with work sharing inside the wave.
+//
+// In walk_kernel a wave lasts as long as its slowest ray, and rays differ wildly: a bounce ray leaves the mesh after
+// twenty-odd nodes on average, while one that skims along the surface and hits nothing pierces hundreds of leaf boxes,
+// one dependent fetch after the other.  Two fifths of the lanes work on average, and a launch alone on the chip lasts
+// eight times its average wave.  Here a lane that has run out of work takes a subtree from a lane that still has
+// some: the donor gives away the BOTTOM entry of its traversal stack (the far child pushed nearest the root, i.e.
+// the largest piece of work it holds; the bottom entries are the ones kept in LDS, where another lane can read
+// them), the thief copies the donor's ray and walks that subtree for it.  All lanes working on a ray prune against
+// the nearest distance any of them has accepted (s_cut, an LDS word per ray), and publish what they found under the
+// reference's rule for equal distances -- the face met later in ITS visiting order wins (src/flyscene.cpp:760),
+// which the per-face rank makes independent of who found what when -- through a 64-bit LDS minimum per ray:
+// (distance bits, inverted rank).  The slowest ray of a wave thus gets up to 63 helpers, doubling per round.
+// Narrow groups (a launch alone on the chip, see walk_kernel) start with most lanes idle, so they share from the start.
+// ---------------------------------------------------------------------------------------------
+#ifndef RT_STEAL_STEPS
+#define RT_STEAL_STEPS 2
+#endif
+#ifndef RT_FACE_TRIGGER
+#define RT_FACE_TRIGGER 8
+#endif
+struct RaySetup {
+    float ix, iy, iz;
+    unsigned offx, offy, offz;
+    float bnx, bny, bnz, bfx, bfy, bfz;
+};
+// Slab-test operands of a ray; see the comment in walk_kernel.
+__device__ __forceinline__ RaySetup setup_ray(V3 o, V3 d) {
+    constexpr float kInvMax = 1e25f;
+    RaySetup r;
+    r.ix = 1.0f / d.x, r.iy = 1.0f / d.y, r.iz = 1.0f / d.z;
+    const bool cx = !(fabsf(r.ix) <= kInvMax), cy = !(fabsf(r.iy) <= kInvMax), cz = !(fabsf(r.iz) <= kInvMax);
+    if (cx) r.ix = copysignf(kInvMax, d.x);
+    if (cy) r.iy = copysignf(kInvMax, d.y);
+    if (cz) r.iz = copysignf(kInvMax, d.z);
+    r.offx = r.ix < 0.0f ? 16u : 0u, r.offy = r.iy < 0.0f ? 48u : 32u, r.offz = r.iz < 0.0f ? 80u : 64u;
+    const float bx = -o.x * r.ix, by = -o.y * r.iy, bz = -o.z * r.iz;
+    const float ex = cx ? 0.0f : 1.2e-7f * fabsf(bx), ey = cy ? 0.0f : 1.2e-7f * fabsf(by), ez = cz ? 0.0f : 1.2e-7f * fabsf(bz);
+    r.bnx = bx - ex, r.bny = by - ey, r.bnz = bz - ez;
+    r.bfx = bx + ex, r.bfy = by + ey, r.bfz = bz + ez;
+    return r;
+}
+// Orders (distance, face) candidates of one ray: nearest first, equal distances by the later face.  Distances are
+// positive, so their bit patterns order like unsigned integers.
+__device__ __forceinline__ unsigned long long hit_key(float t, int rank) {
+    return ((unsigned long long)(unsigned)__float_as_int(t) << 32) | (unsigned long long)(unsigned)(0x7fffffff - rank);
+}
+// Orders this wave's LDS traffic against its own later LDS traffic (the hardware keeps a wave's LDS operations in
+// order; this keeps the compiler from moving them).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_steal_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth, int total_static) {
+    static_assert(MODE == kPrimary || MODE == kQueue, "closest-hit modes only");
+    __shared__ int s_stack[(kLdsStack + kLeafQueueClosest) * 64];
+    __shared__ unsigned long long s_key[64]; // per ray of the wave: best (distance, rank) published so far
+    __shared__ int s_tri[64];                // ... and its record
+    __shared__ int s_cut[64];                // ... and the bits of the nearest distance accepted by any lane, published or not
+    __shared__ int s_donor[64];
+    int deep[kStackEntries - kLdsStack > 0 ? kStackEntries - kLdsStack : 1];
+    const int lane = (int)threadIdx.x;
+    int *const stack = s_stack + lane;
+    int *const leafq = s_stack + kLdsStack * 64 + lane;
+    constexpr int CAP = kLeafQueueClosest;
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    if (MODE == kPrimary && ws.bin_entries && bins_accepted(ws)) return; // raster_kernel does this pass
+    const int rays = MODE == kPrimary ? total_static : ws.stage[stage - 1].next;
+    int shift = 6;
+    if (MODE == kQueue && !ws.full_waves)
+        while (shift > kMinGroupShift && (rays >> shift) < kFullChipWaves) --shift;
+    const int ngroups = (rays + (1 << shift) - 1) >> shift;
+    unsigned w_box = 0, w_plane = 0, w_edge = 0;
+
+    for (int group = (int)blockIdx.x; group < ngroups; group += (int)gridDim.x) {
+        const int item = (group << shift) + lane;
+        V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+        bool valid = lane < (1 << shift);
+        if (MODE == kPrimary) {
+            int x, row;
+            valid = slot_pixel(fc, item, x, row);
+            o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
+            if (valid)
+                d = primary_direction(fc, ws, x, row);
+            else
+                ws.slot_tri[item] = -2; // padding of an edge tile
+        } else {
+            valid = valid && item < rays;
+            if (valid) {
+                const float *qd = ws.queue[depth % 3];
+                o = mk(plane(qd, ws.capacity, 0)[item], plane(qd, ws.capacity, 1)[item], plane(qd, ws.capacity, 2)[item]);
+                d = mk(plane(qd, ws.capacity, 3)[item], plane(qd, ws.capacity, 4)[item], plane(qd, ws.capacity, 5)[item]);
+            }
+        }
+        float tbest = FLT_MAX;
+        int best_tri = -2, best_rank = -1;
+        // intersects(): spheres first, then triangles, sharing the running maximum (:673-676)
+        if (valid && sc.num_spheres > 0 && spheres_hit(sc, o, d, fc.t_eps, tbest)) best_tri = -1;
+        s_key[lane] = best_tri == -1 ? hit_key(tbest, -1) : ~0ull;
+        s_tri[lane] = best_tri;
+        s_cut[lane] = __float_as_int(tbest);
+        int owner = lane; // the ray this lane works for = the lane that loaded it
+        RaySetup rs = setup_ray(o, d);
+        int node = valid ? 0 : kSentinel, sp = 0, base = 0, nq = 0;
+        bool dirty = false; // holds an accepted face that is not published yet
+        float tlimit = tbest * 1.000001f;
+        wave_sync();
+
+        for (;;) {
+            const bool has_work = node != kSentinel || sp > base || nq > 0;
+            // ---- lanes out of work publish what they found
+            if (__ballot(!has_work && dirty) != 0ull) {
+                const unsigned long long key = hit_key(tbest, best_rank);
+                if (!has_work && dirty) atomicMin(&s_key[owner], key);
+                wave_sync();
+                if (!has_work && dirty) {
+                    if (s_key[owner] == key) s_tri[owner] = best_tri;
+                    dirty = false;
+                }
+                wave_sync();
+            }
+            const unsigned long long work = __ballot(has_work);
+            if (work == 0ull) break;
+            // ---- ... and take the bottom of a busy lane's stack
+            const bool can_give = node != kSentinel && sp > base && base < kLdsStack;
+            const unsigned long long donors = __ballot(can_give), idle = ~work;
+            if (idle != 0ull && donors != 0ull) {
+                const int n = min((int)__popcll(idle), (int)__popcll(donors));
+                const int rank_d = (int)__popcll(donors & below), rank_i = (int)__popcll(idle & below);
+                const bool gives = can_give && rank_d < n, thief = !has_work && rank_i < n;
+                if (gives) s_donor[rank_d] = lane;
+                wave_sync();
+                const int src = thief ? s_donor[rank_i] : lane;
+                const float sox = __shfl(o.x, src, 64), soy = __shfl(o.y, src, 64), soz = __shfl(o.z, src, 64);
+                const float sdx = __shfl(d.x, src, 64), sdy = __shfl(d.y, src, 64), sdz = __shfl(d.z, src, 64);
+                const int sowner = __shfl(owner, src, 64), sbase = __shfl(base, src, 64);
+                if (thief) {
+                    o = mk(sox, soy, soz), d = mk(sdx, sdy, sdz);
+                    owner = sowner;
+                    rs = setup_ray(o, d);
+                    node = s_stack[sbase * 64 + src];
+                    sp = base = 0;
+                    tbest = __int_as_float(s_cut[owner]); // nothing farther is of interest; equal distances still are (rank)
+                    best_tri = -2, best_rank = -1;
+                    tlimit = tbest * 1.000001f;
+                }
+                if (gives) ++base;
+            }
+
+            // ---- node phase, a few steps at a time so that idle lanes get their chance
+            {
+                const float cut = __int_as_float(s_cut[owner]);
+                tlimit = fminf(tlimit, cut * 1.000001f);
+            }
+            for (int steps = 0; node != kSentinel && steps < RT_STEAL_STEPS; ++steps) {
+                if (node < 0) {
+                    if ((~node & 15) != 0) { // the builder's placeholder leaf holds no face: never parked
+                        if (nq == CAP) break;
+                        leafq[nq * 64] = node;
+                        ++nq;
+                    }
+                    if (sp == base) {
+                        node = kSentinel;
+                    } else {
+                        --sp;
+                        node = stack_read(stack, deep, sp);
+                    }
+                    continue;
+                }
+                const char *nodes = (const char *)sc.nodes;
+                const unsigned nb = (unsigned)node << 7;
+                const float4 ex4 = *(const float4 *)(nodes + (nb + rs.offx)), fx4 = *(const float4 *)(nodes + ((nb + rs.offx) ^ 16u));
+                const float4 ey4 = *(const float4 *)(nodes + (nb + rs.offy)), fy4 = *(const float4 *)(nodes + ((nb + rs.offy) ^ 16u));
+                const float4 ez4 = *(const float4 *)(nodes + (nb + rs.offz)), fz4 = *(const float4 *)(nodes + ((nb + rs.offz) ^ 16u));
+                const float4 chf = *(const float4 *)(nodes + (nb + 96u));
+                if (COUNT) w_box += (unsigned)__float_as_int((*(const float4 *)(nodes + (nb + 112u))).x);
+                const int c0 = __float_as_int(chf.x), c1 = __float_as_int(chf.y), c2 = __float_as_int(chf.z), c3 = __float_as_int(chf.w);
+                float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
+#define RT_SLAB(K, C)                                                                                                                          \
+    tn##K = fmaxf(fmaxf(__builtin_fmaf(ex4.C, rs.ix, rs.bnx), __builtin_fmaf(ey4.C, rs.iy, rs.bny)), fmaxf(__builtin_fmaf(ez4.C, rs.iz, rs.bnz), 0.0f)); \
+    tf##K = fminf(fminf(__builtin_fmaf(fx4.C, rs.ix, rs.bfx), __builtin_fmaf(fy4.C, rs.iy, rs.bfy)), fminf(__builtin_fmaf(fz4.C, rs.iz, rs.bfz), tlimit));
+                RT_SLAB(0, x)
+                RT_SLAB(1, y)
+                RT_SLAB(2, z)
+                RT_SLAB(3, w)
+#undef RT_SLAB
+                const bool h0 = tn0 <= tf0 * 1.0000005f, h1 = tn1 <= tf1 * 1.0000005f;
+                const bool h2 = tn2 <= tf2 * 1.0000005f, h3 = tn3 <= tf3 * 1.0000005f;
+                const int hits = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+                if (hits == 0) {
+                    if (sp == base) {
+                        node = kSentinel;
+                    } else {
+                        --sp;
+                        node = stack_read(stack, deep, sp);
+                    }
+                } else {
+                    int s0 = h0 ? (__float_as_int(tn0) & ~3) | 0 : 0x7fffffff;
+                    int s1 = h1 ? (__float_as_int(tn1) & ~3) | 1 : 0x7fffffff;
+                    int s2 = h2 ? (__float_as_int(tn2) & ~3) | 2 : 0x7fffffff;
+                    int s3 = h3 ? (__float_as_int(tn3) & ~3) | 3 : 0x7fffffff;
+#define RT_CSWAP(A, B)             \
+    {                              \
+        const int lo_ = min(A, B); \
+        B = max(A, B);             \
+        A = lo_;                   \
+    }
+                    RT_CSWAP(s0, s1)
+                    RT_CSWAP(s2, s3)
+                    RT_CSWAP(s0, s2)
+                    RT_CSWAP(s1, s3)
+                    RT_CSWAP(s1, s2)
+#undef RT_CSWAP
+#define RT_REF(S) (((S)&2) ? (((S)&1) ? c3 : c2) : (((S)&1) ? c1 : c0))
+                    node = RT_REF(s0);
+                    if (hits > 1) stack_write(stack, deep, sp + hits - 2, RT_REF(s1));
+                    if (hits > 2) stack_write(stack, deep, sp + hits - 3, RT_REF(s2));
+                    if (hits > 3) stack_write(stack, deep, sp, RT_REF(s3));
+#undef RT_REF
+                    sp += hits - 1;
+                }
+            }
+
+            // ---- face phase: once no lane can descend any further, or enough of them wait for it; every lane with
+            // parked leaves joins.  Exact plane + three-edge test, src/flyscene.cpp:752-789.
+            const bool descending = node != kSentinel && !(node < 0 && nq == CAP);
+            const bool waiting = nq > 0 && !descending;
+            const unsigned long long m_desc = __ballot(descending), m_wait = __ballot(waiting);
+            if (m_wait != 0ull && (m_desc == 0ull || (int)__popcll(m_wait) >= RT_FACE_TRIGGER)) {
+                const float cut = __int_as_float(s_cut[owner]);
+                int qi = 0, k = 0;
+                while (qi < nq) {
+                    const int ref = ~leafq[qi * 64];
+                    const int i = (ref >> 4) + k;
+                    if (++k == (ref & 15)) {
+                        k = 0;
+                        ++qi;
+                    }
+                    const float4 pn = sc.tris[i * 4 + 0];
+                    const float4 p0 = sc.tris[i * 4 + 1];
+                    const float4 p1 = sc.tris[i * 4 + 2];
+                    const float4 p2 = sc.tris[i * 4 + 3];
+                    if (COUNT) ++w_plane;
+                    const V3 n = mk(pn.x, pn.y, pn.z);
+                    const float t = (pn.w - dot(o, n)) / dot(d, n);
+                    if (!(t >= fc.t_eps && t <= fminf(tbest, cut))) continue; // also rejects NaN (see file header)
+                    const int rank = __float_as_int(p1.w);
+                    if (t == tbest && rank < best_rank) continue; // equal distance: the later face wins (:760)
+                    if (COUNT) ++w_edge;
+                    const V3 v0 = mk(p0.x, p0.y, p0.z), v1 = mk(p1.x, p1.y, p1.z), v2 = mk(p2.x, p2.y, p2.z);
+                    const V3 hp = o + t * d;
+                    if (dot(cross(v1 - v0, hp - v0), n) < 0) continue;
+                    if (dot(cross(v2 - v1, hp - v1), n) < 0) continue;
+                    if (dot(cross(v0 - v2, hp - v2), n) < 0) continue;
+                    tbest = t;
+                    best_tri = i;
+                    best_rank = rank;
+                    tlimit = t * 1.000001f;
+                    dirty = true;
+                    atomicMin(&s_cut[owner], __float_as_int(t));
+                }
+                nq = 0;
+            }
+        }
+
+        wave_sync();
+        if (valid) {
+            const unsigned long long key = s_key[lane];
+            ws.slot_tri[item] = s_tri[lane];
+            ws.slot_t[item] = key == ~0ull ? FLT_MAX : __int_as_float((int)(unsigned)(key >> 32));
+        }
+        wave_sync();
+    }
+    if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Primary rays by screen binning.  All primary rays leave one point, so the faces a pixel's ray can hit are
 // those whose perspective projection covers the pixel.  Per pass: every face is projected, its pixel bounding
 // box (widened far beyond the rounding of the projection and of the exact test) is entered into the bins
@@ -1515,6 +1796,21 @@ void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const 
     if (!primary && expect >= 0) // narrow groups (a launch alone on the chip) hold as few as sixteen rays
         groups = std::min(groups, (with_margin(expect) + (ws.full_waves ? 63 : 15)) / (ws.full_waves ? 64 : 16));
     const int blocks = primary && ws.bin_entries ? (ws.bins_expected ? 2048 : 16384) : walk_grid(groups);
+    static const int steal = getenv("RTAMD_WALK_STEAL") ? atoi(getenv("RTAMD_WALK_STEAL")) : 1; // experiment hook
+    if (steal && fc.t_eps >= 0.0f) { // (the shared nearest distance is ordered by its bits: distances must be positive)
+        if (primary) {
+            if (count)
+                walk_steal_kernel<kPrimary, true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, total_static);
+            else
+                walk_steal_kernel<kPrimary, false><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, total_static);
+        } else {
+            if (count)
+                walk_steal_kernel<kQueue, true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, 0);
+            else
+                walk_steal_kernel<kQueue, false><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, 0);
+        }
+        return;
+    }
     if (primary) {
         if (count)
             walk_kernel<kPrimary, true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, total_static);
