@@ -8,7 +8,6 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
-#include <map>
 #include <mutex>
 #include <cmath>
 #include <cstdarg>
@@ -84,7 +83,6 @@ struct FrameSlot {
     uint64_t feedback_key = 0;    // image size and partition the report belongs to
     uint64_t view_key = 0;        // ... and the camera and pass structure the stage counts belong to
     int frames_without_bins = 0;
-    std::vector<hipEvent_t> sync; // events that order the streams of a frame with reflections
 };
 
 } // namespace
@@ -217,32 +215,6 @@ int check_params(const rtamd_scene *s, const rtamd_camera *cam, const rtamd_rend
     return RTAMD_OK;
 }
 
-// Side streams of frames with reflections: ONE pair per device for the whole process, shared by every scene.
-// A process has few hardware queues (four by default); once the streams in use outnumber them, streams share
-// a queue, and a wait queued ahead of the work it waits for, in the same hardware queue, never ends -- seen
-// with two reflective scenes alive, each with streams of its own.  The side chains are the critical path of
-// such a frame (few rays, long dependent chains), so their waves get dispatch priority over the large
-// depth-0 shadow launch they overlap.
-struct SideStreams {
-    hipStream_t geometry = nullptr, deep_shadow = nullptr;
-};
-int side_streams(int device, SideStreams **out) {
-    static std::mutex lock;
-    static std::map<int, SideStreams> per_device;
-    std::lock_guard<std::mutex> guard(lock);
-    SideStreams &ss = per_device[device];
-    if (!ss.geometry) {
-        int least = 0, greatest = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        (void)least;
-        const int prio = greatest;
-        HIP_TRY(hipStreamCreateWithPriority(&ss.geometry, hipStreamNonBlocking, prio));
-        HIP_TRY(hipStreamCreateWithPriority(&ss.deep_shadow, hipStreamNonBlocking, prio));
-    }
-    *out = &ss;
-    return RTAMD_OK;
-}
-
 // The slot that serves `stream`.  When all slots are taken the least recently used one changes hands, after the
 // host has waited for its last frame: no stream ever waits for another one here.
 int acquire_slot(rtamd_scene *s, hipStream_t stream, FrameSlot **out) {
@@ -259,8 +231,6 @@ int acquire_slot(rtamd_scene *s, hipStream_t stream, FrameSlot **out) {
         s->slots[pick].feedback = (volatile int32_t *)host;
         s->slots[pick].ws.bin_feedback = (int32_t *)mapped;
         s->slots[pick].ws.stage_feedback = (int32_t *)mapped + kStageFeedbackAt;
-        // the first slot's frames may use the side streams: let them end before a second caller stream joins
-        if (pick == 1 && s->slots[0].used) HIP_TRY(hipEventSynchronize(s->slots[0].done));
     }
     if (pick < 0) {
         pick = 0;
@@ -614,7 +584,6 @@ int rtamd_scene_destroy(rtamd_scene *s) {
         if (fs.block) (void)hipFree(fs.block);
         if (fs.done) (void)hipEventDestroy(fs.done);
         if (fs.feedback) (void)hipHostFree((void *)fs.feedback);
-        for (hipEvent_t e : fs.sync) (void)hipEventDestroy(e);
     }
     if (s->h_staging) (void)hipHostFree(s->h_staging);
     for (TimedLaunch &t : s->events) {
@@ -723,8 +692,7 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
             fs.feedback[0] = fs.feedback[1] = fs.feedback[2] = fs.feedback[3] = 0;
             fs.frames_without_bins = 0;
         }
-        const long long total = fs.feedback[0], nonempty = fs.feedback[1];
-        const bool turned_down = fs.feedback[3] != 0 && (fs.feedback[2] != 0 || total > (long long)kMaxAverageBinList * std::max(nonempty, 1ll));
+        const bool turned_down = fs.feedback[3] != 0 && fs.feedback[2] != 0; // [2]: the pass's own verdict (bins_accepted)
         bins_kept_before = fs.feedback[3] != 0 && !turned_down;
         if (turned_down && fs.frames_without_bins < 63) { // try the bins again every 64th frame: the camera may have moved
             bins_ok = false;
@@ -764,7 +732,6 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
     const bool count = (p->flags & RTAMD_FLAG_COUNT_WORK) != 0;
     const bool timed = !plain && (p->flags & RTAMD_FLAG_TIME_KERNELS) != 0;
     size_t open_slot = 0;
-    hipStream_t stream_of_launch = stream; // timing events are recorded on the stream their kernel runs on
     auto begin = [&](int kind) -> int {
         if (!timed) return RTAMD_OK;
         if (s->events_used == s->events.size()) {
@@ -776,12 +743,12 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
         }
         open_slot = s->events_used++;
         s->events[open_slot].kind = kind;
-        HIP_TRY(hipEventRecord(s->events[open_slot].start, stream_of_launch));
+        HIP_TRY(hipEventRecord(s->events[open_slot].start, stream));
         return RTAMD_OK;
     };
     auto end = [&]() -> int {
         if (!timed) return RTAMD_OK;
-        HIP_TRY(hipEventRecord(s->events[open_slot].stop, stream_of_launch));
+        HIP_TRY(hipEventRecord(s->events[open_slot].stop, stream));
         return RTAMD_OK;
     };
     size_t frame_slot = 0;
@@ -792,31 +759,13 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
 
     // Per SSAA pass the work of depth d is walk(d) -> compact(d) (which also spawns the rays of depth d+1) ->
     // shadow walk(d) -> shade(d).  Only shade(d) needs shade(d-1) (it hands down the throughput); walk(d+1) and
-    // shadow walk(d) both need just compact(d).  With reflections the closest-hit chain therefore runs ahead
-    // on a second stream and the shadow walks of depth >= 1 on a third, so that the small, latency-bound
-    // launches of the deeper stages overlap the large shadow launch of depth 0 on the caller's stream, where
-    // all shading runs in order.  Buffers rotate (hit lists and shadow results by d & 1, queues by d % 3):
-    // compact(d + 2) is the first kernel to overwrite what shade(d) reads, and waits for it.
-    static const bool serial = getenv("RTAMD_SERIAL") != nullptr; // experiment hook: everything on the caller's stream
-    // Side streams only for a scene that is rendered on ONE caller stream.  A caller with several streams overlaps
-    // whole frames instead, each entirely on its own stream: the streams in use then outnumber the hardware
-    // queues, and waits between streams that share a queue are what must not happen (see side_streams).
-    const bool two_streams = !plain && depths > 1 && !serial && (p->flags & RTAMD_FLAG_SINGLE_STREAM) == 0 && s->num_slots == 1;
-    hipStream_t geo = stream, deep = stream;
-    if (two_streams) {
-        SideStreams *side = nullptr;
-        if ((rc = side_streams(s->device, &side)) != RTAMD_OK) return rc;
-        geo = side->geometry;
-        deep = side->deep_shadow;
-        while (fs.sync.size() < (size_t)(3 * depths + 1)) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            fs.sync.push_back(e);
-        }
-    }
-    auto compacted = [&](int d) { return fs.sync[(size_t)(1 + 3 * d)]; };
-    auto shaded = [&](int d) { return fs.sync[(size_t)(2 + 3 * d)]; };
-    auto shadowed = [&](int d) { return fs.sync[(size_t)(3 + 3 * d)]; };
+    // shadow walk(d) both need just compact(d), and compact(d+1) and shade(d) do not touch each other's data.
+    // Buffers rotate (hit lists and shadow results by d & 1, queues by d % 3): compact(d + 2) is the first kernel to
+    // overwrite what shade(d) reads.  Everything is enqueued on the caller's stream: independent pieces share a
+    // launch (below) instead of running on streams of the library's own, which stalled for good whenever the
+    // process's streams outnumbered its hardware queues and a wait shared a queue with the work it waited for.
+    static const bool fuse_off = getenv("RTAMD_FUSE") && atoi(getenv("RTAMD_FUSE")) == 0; // experiment hook
+    const bool fuse = !timed && !fuse_off; // (timed frames keep one kernel per launch, so that every kernel can be timed)
     const bool deep_bg = p->background_deep[0] != 0.0f || p->background_deep[1] != 0.0f || p->background_deep[2] != 0.0f;
 
     // Every pass starts with prep_kernel: it fills the pass's screen-coordinate tables and zeroes the bin counters; the first
@@ -828,50 +777,62 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
             fc.sub_x = (float)xs / S; // src/flyscene.cpp:816-817
             fc.sub_y = (float)ys / S;
             fc.accumulate = (xs | ys) != 0;
-            if (two_streams) { // everything enqueued so far (previous frame, previous pass shaded) precedes this pass
-                HIP_TRY(hipEventRecord(fs.sync[0], stream));
-                HIP_TRY(hipStreamWaitEvent(geo, fs.sync[0], 0));
-            }
             if (stage == 0)
-                launch_prep(fc, ws_frame, fs.block, 4096 + bin_clear, geo);
+                launch_prep(fc, ws_frame, fs.block, 4096 + bin_clear, stream);
             else
-                launch_prep(fc, ws_frame, (char *)fs.block + 4096, bin_clear, geo);
-            for (int d = 0; d < depths; ++d, ++stage) {
+                launch_prep(fc, ws_frame, (char *)fs.block + 4096, bin_clear, stream);
+            // Fused form: the shadow rays of level d share a launch with the closest hits of level d + 1, and the shading of
+            // level d with the compaction of level d + 1 (each pair needs only what the launch before it produced), all on
+            // the caller's stream.  The GPU runs only a few kernels at a time however many streams feed it, so what a frame
+            // costs other frames in flight is the SUM of its launches' durations: pairing the long, mostly idle chain of a
+            // bounce walk with the shadow rays beside it takes that sum down by a fifth, and a frame alone gets the overlap
+            // the side streams below were made for.
+            for (int d = 0; fuse && d < depths; ++d, ++stage) {
+                const bool spawn = d + 1 < depths;
+                if (d == 0) {
+                    if (bins_ok) launch_primary_bins(count, s->ds, fc, ws_frame, s->info.num_device_faces, /*cleared=*/true, stream);
+                    // the tree walk behind the bins runs only where the pass turns its bins down; the same view kept them before
+                    if (!(bins_ok && ws_frame.bins_expected)) launch_walk_closest(true, count, s->ds, fc, ws_frame, stage, 0, -1, stream);
+                    launch_compact(true, s->ds, fc, ws_frame, stage, 0, spawn, false, rgb, face_id, t_hit, -1, stream);
+                }
+                const int hits_here = expect_hits[(size_t)stage], rays_next = expect_next[(size_t)stage];
+                if (spawn && can_fuse_shadow_walk(s->ds, fc)) {
+                    launch_shadow_walk(count, s->ds, fc, ws_frame, stage, d, hits_here, rays_next, stream);
+                } else {
+                    if (nshadow > 0) launch_walk_shadow(count, s->ds, fc, ws_frame, stage, d, hits_here, stream);
+                    if (spawn) launch_walk_closest(false, count, s->ds, fc, ws_frame, stage + 1, d + 1, rays_next, stream);
+                }
+                if (spawn && can_fuse_shade_compact(ws_frame)) {
+                    launch_shade_compact(d == 0, s->ds, fc, ws_frame, stage, d, d + 2 < depths, deep_bg, rgb, hits_here, rays_next, stream);
+                } else {
+                    launch_shade(d == 0, s->ds, fc, ws_frame, stage, d, spawn, rgb, hits_here, stream);
+                    if (spawn) launch_compact(false, s->ds, fc, ws_frame, stage + 1, d + 1, d + 2 < depths, deep_bg, rgb, face_id, t_hit, rays_next, stream);
+                }
+                if (deep_bg && d > 0) launch_misses(fc, ws_frame, stage, d, rgb, expect_next[(size_t)stage - 1], stream);
+            }
+            for (int d = 0; !fuse && d < depths; ++d, ++stage) {
                 const bool spawn = d + 1 < depths;
                 // ---- closest hits
-                stream_of_launch = geo;
                 if ((rc = begin(d == 0 && bins_ok ? 6 : 0)) != RTAMD_OK) return rc;
-                if (d == 0 && bins_ok) launch_primary_bins(count, s->ds, fc, ws_frame, s->info.num_device_faces, /*cleared=*/true, geo);
-                launch_walk_closest(d == 0, count, s->ds, fc, ws_frame, stage, d, d > 0 ? expect_next[(size_t)stage - 1] : -1, geo); // after the bins: only on their overflow
+                if (d == 0 && bins_ok) launch_primary_bins(count, s->ds, fc, ws_frame, s->info.num_device_faces, /*cleared=*/true, stream);
+                launch_walk_closest(d == 0, count, s->ds, fc, ws_frame, stage, d, d > 0 ? expect_next[(size_t)stage - 1] : -1, stream); // after the bins: only on their overflow
                 if ((rc = end()) != RTAMD_OK) return rc;
-                if (two_streams && d >= 2) HIP_TRY(hipStreamWaitEvent(geo, shaded(d - 2), 0));
                 if ((rc = begin(2)) != RTAMD_OK) return rc;
-                launch_compact(d == 0, s->ds, fc, fs.ws, stage, d, spawn, deep_bg && d > 0, rgb, face_id, t_hit, d > 0 ? expect_next[(size_t)stage - 1] : -1, geo);
+                launch_compact(d == 0, s->ds, fc, ws_frame, stage, d, spawn, deep_bg && d > 0, rgb, face_id, t_hit, d > 0 ? expect_next[(size_t)stage - 1] : -1, stream);
                 if ((rc = end()) != RTAMD_OK) return rc;
-                if (two_streams) HIP_TRY(hipEventRecord(compacted(d), geo));
-                // ---- shadow rays: depth 0 on the caller's stream, deeper ones beside it
-                hipStream_t sh = d == 0 ? stream : deep;
-                if (two_streams) HIP_TRY(hipStreamWaitEvent(sh, compacted(d), 0));
+                // ---- shadow rays
                 if (nshadow > 0) {
-                    stream_of_launch = sh;
                     if ((rc = begin(1)) != RTAMD_OK) return rc;
-                    launch_walk_shadow(count, s->ds, fc, fs.ws, stage, d, expect_hits[(size_t)stage], sh);
+                    launch_walk_shadow(count, s->ds, fc, ws_frame, stage, d, expect_hits[(size_t)stage], stream);
                     if ((rc = end()) != RTAMD_OK) return rc;
                 }
-                if (two_streams && d > 0) {
-                    HIP_TRY(hipEventRecord(shadowed(d), deep));
-                    HIP_TRY(hipStreamWaitEvent(stream, shadowed(d), 0));
-                }
                 // ---- shading, in depth order
-                stream_of_launch = stream;
                 if ((rc = begin(3)) != RTAMD_OK) return rc;
-                launch_shade(d == 0, s->ds, fc, fs.ws, stage, d, spawn, rgb, expect_hits[(size_t)stage], stream);
-                if (deep_bg && d > 0) launch_misses(fc, fs.ws, stage, d, rgb, expect_next[(size_t)stage - 1], stream);
+                launch_shade(d == 0, s->ds, fc, ws_frame, stage, d, spawn, rgb, expect_hits[(size_t)stage], stream);
+                if (deep_bg && d > 0) launch_misses(fc, ws_frame, stage, d, rgb, expect_next[(size_t)stage - 1], stream);
                 if ((rc = end()) != RTAMD_OK) return rc;
-                if (two_streams) HIP_TRY(hipEventRecord(shaded(d), stream));
             }
         }
-    stream_of_launch = stream;
     if (S > 1) {
         if ((rc = begin(4)) != RTAMD_OK) return rc;
         launch_scale(rgb, pixels * 3, (float)(S * S), stream);
@@ -980,7 +941,7 @@ int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
         st->bins_nonempty = (uint32_t)bs.nonempty;
         st->bin_overflow = bs.fallback;
         const long long limit = s->bin_always ? 0x7fffffffll : (long long)kMaxAverageBinList;
-        st->primary_path = !bs.fallback && (long long)bs.total <= limit * (long long)std::max(bs.nonempty, 1) ? 1 : 0;
+        st->primary_path = !bs.fallback && (long long)bs.num_big <= 4 * limit && (long long)bs.total <= limit * (long long)std::max(bs.nonempty, 1) ? 1 : 0;
     }
     for (size_t i = 0; i < s->events_used; ++i) {
         float ms = 0.0f;

@@ -25,6 +25,15 @@ void launch_walk_shadow(bool count, const DeviceScene &sc, const FrameConst &fc,
                         hipStream_t stream);
 void launch_shade(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, bool spawn, float *rgb,
                   int expect, hipStream_t stream);
+// One launch for two independent pieces of a frame (see shadow_walk_kernel, shade_compact_kernel in kernels.hip): the shadow
+// rays of level `depth` with the closest hits of level depth + 1, and the shading of level `depth` with the compaction of
+// level depth + 1.  `stage` is the stage of level `depth`; the other piece works on stage + 1.
+bool can_fuse_shadow_walk(const DeviceScene &sc, const FrameConst &fc);
+bool can_fuse_shade_compact(const Workspace &ws);
+void launch_shadow_walk(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, int expect_hits,
+                        int expect_next, hipStream_t stream);
+void launch_shade_compact(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, bool spawn_next,
+                          bool list_misses, float *rgb, int expect_hits, int expect_next, hipStream_t stream);
 void launch_misses(const FrameConst &fc, const Workspace &ws, int stage, int depth, float *rgb, int expect, hipStream_t stream);
 void launch_scale(float *rgb, size_t n, float divisor, hipStream_t stream);
 void launch_quantize(const float *rgb, uint8_t *out, size_t n, hipStream_t stream);

@@ -166,7 +166,9 @@ __device__ __forceinline__ bool spheres_hit(const DeviceScene &sc, V3 o, V3 d, f
 // long that walking the tree is cheaper (a small image of a dense mesh).  Known after bin_offsets_kernel.
 __device__ __forceinline__ bool bins_accepted(const Workspace &ws) {
     const BinState *st = ws.bin_state;
-    return !st->fallback && (long long)st->total <= (long long)ws.bin_max_list * (long long)max(st->nonempty, 1);
+    // (the big-face list is scanned by every pixel on top of its bin's list)
+    return !st->fallback && (long long)st->num_big <= 4ll * (long long)ws.bin_max_list &&
+           (long long)st->total <= (long long)ws.bin_max_list * (long long)max(st->nonempty, 1);
 }
 
 __device__ __forceinline__ void flush_work(unsigned a, unsigned b, unsigned c, WorkCounters *out) {
@@ -592,8 +594,10 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// (`block` of `nblocks`: the launch's block index and grid, or this kernel's share of a launch it shares with another)
 template <int MODE, bool COUNT>
-__global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_steal_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth, int total_static) {
+__device__ __forceinline__ void walk_steal_body(const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, int total_static,
+                                                int block, int nblocks) {
     static_assert(MODE == kPrimary || MODE == kQueue, "closest-hit modes only");
     __shared__ int s_stack[(kLdsStack + kLeafQueueClosest) * 64];
     __shared__ unsigned long long s_key[64]; // per ray of the wave: best (distance, rank) published so far
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_steal_kernel(Devic
     const int ngroups = (rays + (1 << shift) - 1) >> shift;
     unsigned w_box = 0, w_plane = 0, w_edge = 0;
 
-    for (int group = (int)blockIdx.x; group < ngroups; group += (int)gridDim.x) {
+    for (int group = block; group < ngroups; group += nblocks) {
         const int item = (group << shift) + lane;
         V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
         bool valid = lane < (1 << shift);
@@ -817,6 +821,11 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_steal_kernel(Devic
     if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 0);
 }
 
+template <int MODE, bool COUNT>
+__global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_steal_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth, int total_static) {
+    walk_steal_body<MODE, COUNT>(sc, fc, ws, stage, depth, total_static, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Primary rays by screen binning.  All primary rays leave one point, so the faces a pixel's ray can hit are
 // those whose perspective projection covers the pixel.  Per pass: every face is projected, its pixel bounding
@@ -849,7 +858,8 @@ struct PixelBox {
 constexpr float kBinMargin = RT_BIN_MARGIN;
 
 // pixel position of a world point: inverse of camera_direction.  false: the point is not in front of the eye.
-__device__ __forceinline__ bool project_point(const FrameConst &fc, V3 p, float &px, float &py) {
+// `behind`: the point lies behind the eye plane by far more than any rounding here or in the exact test.
+__device__ __forceinline__ bool project_point(const FrameConst &fc, V3 p, float &px, float &py, bool &behind) {
     const V3 r = p - mk(fc.origin[0], fc.origin[1], fc.origin[2]);
     const float *m = fc.lin_inv;
     const float qx = m[0] * r.x + (m[1] * r.y + m[2] * r.z);
@@ -858,6 +868,7 @@ __device__ __forceinline__ bool project_point(const FrameConst &fc, V3 p, float 
     // r = s * L * (n + e) with n.z = -1  ->  q = s * (n + e)
     const float s = qz / (fc.cam_e[2] - 1.0f);
     const float reach = fabsf(qx) + fabsf(qy) + fabsf(qz);
+    behind = s < -1e-4f * reach;
     if (!(s > 1e-6f * reach)) return false;
     const float nx = qx / s - fc.cam_e[0], ny = qy / s - fc.cam_e[1];
     px = fc.vp[0] + (nx / fc.ax + 1.0f) * (0.5f * fc.vp[2]);
@@ -870,10 +881,19 @@ __device__ __forceinline__ PixelBox face_bins(const DeviceScene &sc, const Frame
     b.empty = false, b.big = false, b.cull = false;
     const float4 p0 = sc.tris[tri * 4 + 1], p1 = sc.tris[tri * 4 + 2], p2 = sc.tris[tri * 4 + 3];
     float x0 = 0, y0 = 0, x1 = 0, y1 = 0, x2 = 0, y2 = 0;
-    const bool ok0 = project_point(fc, mk(p0.x, p0.y, p0.z), x0, y0);
-    const bool ok1 = project_point(fc, mk(p1.x, p1.y, p1.z), x1, y1);
-    const bool ok2 = project_point(fc, mk(p2.x, p2.y, p2.z), x2, y2);
+    bool back0, back1, back2;
+    const bool ok0 = project_point(fc, mk(p0.x, p0.y, p0.z), x0, y0, back0);
+    const bool ok1 = project_point(fc, mk(p1.x, p1.y, p1.z), x1, y1, back1);
+    const bool ok2 = project_point(fc, mk(p2.x, p2.y, p2.z), x2, y2, back2);
     const bool ok = ok0 && ok1 && ok2;
+    // Every point a primary ray reaches at a positive distance lies in front of the eye plane (s > 0 above, and s is
+    // linear in the point); a face with all three corners clearly behind that plane lies behind it entirely and can
+    // meet no such ray.  Without this, a view from inside or past the mesh sent those faces to the list every pixel scans.
+    if (back0 && back1 && back2) {
+        b.empty = true;
+        b.x0 = b.y0 = 0, b.x1 = b.y1 = -1;
+        return b;
+    }
     float xlo = 0.0f, ylo = 0.0f, xhi = (float)fc.width, yhi = (float)fc.height;
     if (ok) {
         // pixel (x, y) samples at (x + sub_x, y + sub_y): shift the box instead of the samples; the margin covers
@@ -1062,7 +1082,7 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(DeviceScene sc, FrameCons
     const int tri = (int)(blockIdx.x * 256 + threadIdx.x);
     if (tri == 0 && ws.bin_feedback) {
         ws.bin_feedback[0] = ws.bin_state->total, ws.bin_feedback[1] = ws.bin_state->nonempty;
-        ws.bin_feedback[2] = ws.bin_state->fallback, ws.bin_feedback[3] = 1;
+        ws.bin_feedback[2] = bins_accepted(ws) ? 0 : 1, ws.bin_feedback[3] = 1;
     }
     if (!bins_accepted(ws)) return;
     if (AGG) {
@@ -1177,6 +1197,112 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst 
     if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 2);
 }
 
+// The same pass with the lists staged through LDS.  In raster_kernel every pixel of a bin walks the bin's list on its
+// own: index, plane, vertices, one dependent fetch after the other, a dozen faces per bin and more -- forty round trips
+// to memory for a wave over the mesh, which is what the pass lasts.  Here a wave is one 8x8 tile = four bins, and its
+// 64 lanes first fetch 64 entries of the four lists (and of the big-face list) at once, whole records, one lane per
+// entry, into LDS; then every pixel runs the exact test over its own bin's share of them from LDS.  Two round trips to
+// memory per 64 candidates.  The faces a pixel tests are the same, and so is the arithmetic: same planes as raster_kernel.
+// Needs the tile's eight local rows to be eight consecutive image rows starting at a multiple of eight: the whole
+// image, or a row partition whose tiles are multiples of eight rows (the caller checks).
+template <bool COUNT>
+__global__ __launch_bounds__(256) void raster_tile_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int total_static) {
+    __shared__ float4 s_pn[4][64], s_p0[4][64], s_p1[4][64], s_p2[4][64];
+    __shared__ int2 s_range[4][64];
+    if (!bins_accepted(ws)) return;
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int slot = (int)(blockIdx.x * 256 + threadIdx.x);
+    unsigned w_box = 0, w_plane = 0, w_edge = 0;
+    if (slot - lane < total_static) { // the wave's tile exists (tiles are whole: every lane has a slot)
+        int x, row;
+        const bool valid = slot_pixel(fc, slot, x, row);
+        const int gy = global_row(fc, row);
+        const int bx = x / kBinPixels, by = gy / kBinPixels;
+        // the tile's four bins: quadrant q = (lane >> 5) * 2 + ((lane >> 2) & 1), first lanes 0, 4, 32, 36.  A quadrant whose
+        // first lane lies outside the image holds no pixel at all.
+        int mine_n = 0, mine_at = 0;
+        if (valid) {
+            const int bin = by * fc.bins_x + bx;
+            mine_n = ws.bin_count[bin];
+            mine_at = ws.bin_start[bin];
+        }
+        const int nbig = ws.bin_state->num_big;
+        const int n0 = __shfl(mine_n, 0, 64), n1 = __shfl(mine_n, 4, 64), n2 = __shfl(mine_n, 32, 64), n3 = __shfl(mine_n, 36, 64);
+        const int a0 = __shfl(mine_at, 0, 64), a1 = __shfl(mine_at, 4, 64), a2 = __shfl(mine_at, 32, 64), a3 = __shfl(mine_at, 36, 64);
+        const int e1 = n0, e2 = n0 + n1, e3 = e2 + n2, total = e3 + n3; // ends of the quadrants' shares of the concatenated list
+        const int q = ((lane >> 5) << 1) | ((lane >> 2) & 1);
+        const int my_lo = q == 0 ? 0 : q == 1 ? e1 : q == 2 ? e2 : e3, my_hi = my_lo + mine_n;
+        if (COUNT && valid) ++w_box;
+        float tbest = FLT_MAX;
+        int best_tri = -2, best_rank = -1;
+        const bool shoots = valid && (mine_n + nbig > 0 || sc.num_spheres > 0);
+        if (__ballot(shoots) != 0ull) { // most tiles of most frames see no face at all: no candidates, no rays
+            const V3 o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
+            V3 d = mk(0, 0, 1);
+            if (shoots) d = primary_direction(fc, ws, x, row);
+            // intersects(): spheres first, then triangles, sharing the running maximum (:673-676)
+            if (shoots && sc.num_spheres > 0 && spheres_hit(sc, o, d, fc.t_eps, tbest)) best_tri = -1;
+            for (int c = 0; c < total + nbig; c += 64) {
+                // ---- stage entries c .. c + 63: one lane, one record
+                const int j = c + lane;
+                int idx = -1;
+                int2 range = make_int2(0, 0);
+                if (j < total) {
+                    const int at = j < e1 ? a0 + j : j < e2 ? a1 + (j - e1) : j < e3 ? a2 + (j - e2) : a3 + (j - e3);
+                    idx = ws.bin_entries[at];
+                } else if (j < total + nbig) {
+                    const int4 g = ws.big[j - total];
+                    idx = g.x;
+                    range = make_int2(g.y, g.z);
+                }
+                if (idx >= 0) {
+                    const float4 *rec = sc.tris + (size_t)idx * 4;
+                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                    float4 r3 = rec[3];
+                    r3.w = __int_as_float(idx); // the record's spare word carries its index
+                    s_pn[wave][lane] = r0, s_p0[wave][lane] = r1, s_p1[wave][lane] = r2, s_p2[wave][lane] = r3;
+                    s_range[wave][lane] = range;
+                }
+                wave_sync();
+                // ---- every pixel: its bin's entries of this chunk, then the chunk's big faces that reach its bin
+                const int lo = max(my_lo, c) - c, hi = min(my_hi, c + 64) - c;
+                const int big_lo = max(total, c) - c, big_hi = min(total + nbig, c + 64) - c;
+                const int count = shoots ? max(hi - lo, 0) + max(big_hi - big_lo, 0) : 0;
+                for (int k = 0; k < count; ++k) {
+                    const bool listed = k < hi - lo;
+                    const int jj = listed ? lo + k : big_lo + (k - max(hi - lo, 0));
+                    if (!listed) {
+                        const int2 g = s_range[wave][jj];
+                        if (bx < (g.x & 0xffff) || bx > (g.y & 0xffff) || by < (g.x >> 16) || by > (g.y >> 16)) continue;
+                    }
+                    // exact plane + three-edge test, src/flyscene.cpp:752-789
+                    const float4 pn = s_pn[wave][jj];
+                    if (COUNT) ++w_plane;
+                    const V3 n = mk(pn.x, pn.y, pn.z);
+                    const float t = (pn.w - dot(o, n)) / dot(d, n);
+                    if (!(t >= fc.t_eps && t <= tbest)) continue; // also rejects NaN (see file header)
+                    const float4 r0 = s_p0[wave][jj], r1 = s_p1[wave][jj], r2 = s_p2[wave][jj];
+                    const int rank = __float_as_int(r1.w);
+                    if (t == tbest && rank < best_rank) continue; // equal distance: the later face wins (:760)
+                    if (COUNT) ++w_edge;
+                    const V3 v0 = mk(r0.x, r0.y, r0.z), v1 = mk(r1.x, r1.y, r1.z), v2 = mk(r2.x, r2.y, r2.z);
+                    const V3 hp = o + t * d;
+                    if (dot(cross(v1 - v0, hp - v0), n) < 0) continue;
+                    if (dot(cross(v2 - v1, hp - v1), n) < 0) continue;
+                    if (dot(cross(v0 - v2, hp - v2), n) < 0) continue;
+                    tbest = t;
+                    best_tri = __float_as_int(r2.w);
+                    best_rank = rank;
+                }
+                wave_sync();
+            }
+        }
+        ws.slot_tri[slot] = best_tri; // -2 also for the padding of an edge tile
+        if (valid) ws.slot_t[slot] = tbest;
+    }
+    if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 2);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Shadow rays through the candidate grids (shadow_grid.hpp).  All shadow rays of one light sample are
 // parallel (their direction is the sample's position, src/flyscene.cpp:884), so the faces that can occlude a
@@ -1192,7 +1318,7 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst 
 #define RT_SHADOW_BATCH 3
 #endif
 template <bool COUNT>
-__global__ __launch_bounds__(64) void shadow_grid_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth) {
+__device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, int block, int nblocks) {
     const int lane = (int)threadIdx.x;
     const int nshadow = sc.num_lights * sc.spl;
     const int nhits = ws.stage[stage].hits;
@@ -1206,7 +1332,7 @@ __global__ __launch_bounds__(64) void shadow_grid_kernel(DeviceScene sc, FrameCo
     const int chunks = (nhits + (1 << per_wave_shift) - 1) >> per_wave_shift;
     const int ngroups = chunks * nshadow;
     unsigned w_box = 0, w_plane = 0, w_edge = 0;
-    for (int group = (int)blockIdx.x; group < ngroups; group += (int)gridDim.x) {
+    for (int group = block; group < ngroups; group += nblocks) {
         // sample-major: the waves in flight at one time work on one grid, not on all of them (8 lights at 8K: -12 %)
         const int sample = group / chunks, chunk = group - sample * chunks;
         const int hit = (chunk << per_wave_shift) + (lane >> split_shift);
@@ -1274,6 +1400,25 @@ __global__ __launch_bounds__(64) void shadow_grid_kernel(DeviceScene sc, FrameCo
         if (valid && sub == 0) ws.clear[depth & 1][sample * ws.capacity + hit] = any ? 0 : 1;
     }
     if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 1);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(64) void shadow_grid_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth) {
+    shadow_grid_body<COUNT>(sc, fc, ws, stage, depth, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Two independent pieces of a frame in one launch: the shadow rays of recursion level `depth` and the closest hits of
+// the reflection rays it spawned (level depth + 1).  Both need only the compaction of level `depth`; launched one
+// after the other each would hold one of the few kernels the GPU runs at a time for as long as its slowest wave, with
+// most of the chip idle behind it.  The first `walk_blocks` workgroups walk (their long chains start first), the rest
+// cast shadow rays.
+template <bool COUNT>
+__global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void shadow_walk_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth,
+                                                                            int walk_blocks) {
+    if ((int)blockIdx.x < walk_blocks)
+        walk_steal_body<kQueue, COUNT>(sc, fc, ws, stage + 1, depth + 1, 0, (int)blockIdx.x, walk_blocks);
+    else
+        shadow_grid_body<COUNT>(sc, fc, ws, stage, depth, (int)blockIdx.x - walk_blocks, (int)gridDim.x - walk_blocks);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1402,15 +1547,15 @@ __global__ __launch_bounds__(64) void shadow_pool_kernel(DeviceScene sc, FrameCo
 // kCompactSegments = 256-slot segments per workgroup (one atomic per list and workgroup): many for large
 // images, where the atomics would dominate, few for small ones, which need the workgroups to fill the chip.
 template <bool PRIMARY, int kCompactSegments>
-__global__ __launch_bounds__(256) void compact_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth, int spawn, int list_misses,
-                                                      float *rgb, int32_t *face_id, float *t_hit, int total_static) {
+__device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, int spawn, int list_misses,
+                                             float *rgb, int32_t *face_id, float *t_hit, int total_static, int block, int nblocks) {
     __shared__ int s_count[3][kCompactSegments][4]; // list (hits, spawned rays, misses) x segment x wave
     __shared__ int s_base[3];
     const int total = PRIMARY ? total_static : ws.stage[stage - 1].next;
     const HitList hl = ws.hits[depth & 1];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the grid may be smaller than the work (it is sized from what earlier frames of the view needed): stride over it
-    for (int first = (int)blockIdx.x * (256 * kCompactSegments); first < total; first += (int)gridDim.x * (256 * kCompactSegments)) {
+    for (int first = block * (256 * kCompactSegments); first < total; first += nblocks * (256 * kCompactSegments)) {
 
     // ---- pass 1: classify the slots of every segment, count per wave
     int tri_of[kCompactSegments];
@@ -1522,6 +1667,12 @@ __global__ __launch_bounds__(256) void compact_kernel(DeviceScene sc, FrameConst
     }
 }
 
+template <bool PRIMARY, int kCompactSegments>
+__global__ __launch_bounds__(256) void compact_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth, int spawn, int list_misses,
+                                                      float *rgb, int32_t *face_id, float *t_hit, int total_static) {
+    compact_body<PRIMARY, kCompactSegments>(sc, fc, ws, stage, depth, spawn, list_misses, rgb, face_id, t_hit, total_static, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // A bounce ray that hits nothing adds throughput * background_deep (zero in the reference,
 // src/flyscene.cpp:661-665, so this kernel only runs when a caller sets that colour).
 __global__ __launch_bounds__(256) void miss_kernel(FrameConst fc, Workspace ws, int stage, int depth, float *rgb) {
@@ -1540,16 +1691,24 @@ __global__ __launch_bounds__(256) void miss_kernel(FrameConst fc, Workspace ws, 
 // Shading: one lane per entry of the hit list.
 // ---------------------------------------------------------------------------------------------
 template <bool PRIMARY>
-__global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth, int spawn, float *rgb) {
+__device__ __forceinline__ void shade_body(const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, int spawn, float *rgb, int block,
+                                           int nblocks) {
     const int nhits = ws.stage[stage].hits;
     // Report what this stage held to the host (page-locked memory, never read by the device): the next frames of the
     // view size their launches from it instead of from the worst case.  Stored + 1: zero means "nothing reported yet".
-    if (blockIdx.x == 0 && threadIdx.x == 0 && ws.stage_feedback) {
+    if (block == 0 && threadIdx.x == 0 && ws.stage_feedback) {
         ws.stage_feedback[2 * stage] = nhits + 1;
         ws.stage_feedback[2 * stage + 1] = ws.stage[stage].next + 1;
     }
     const HitList hl = ws.hits[depth & 1];
-    for (int idx = (int)(blockIdx.x * 256 + threadIdx.x); idx < nhits; idx += (int)gridDim.x * 256) {
+#ifdef RT_BURN
+    { // experiment: dependent multiply-adds on every lane, to see what an added VALU instruction costs a frame
+        float acc = (float)threadIdx.x;
+        for (int k = 0; k < RT_BURN; ++k) acc = __builtin_fmaf(acc, 1.0000001f, 0.5f);
+        if (acc == 12345.678f) rgb[0] = acc;
+    }
+#endif
+    for (int idx = block * 256 + (int)threadIdx.x; idx < nhits; idx += nblocks * 256) {
 
     const V3 P = mk(plane(hl.p, ws.capacity, 0)[idx], plane(hl.p, ws.capacity, 1)[idx], plane(hl.p, ws.capacity, 2)[idx]);
     // getLightIntensity, src/flyscene.cpp:870-896: share of unoccluded samples per light, summed, capped at 1
@@ -1655,6 +1814,23 @@ __global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, FrameConst f
         }
     }
     }
+}
+
+template <bool PRIMARY>
+__global__ __launch_bounds__(256) void shade_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth, int spawn, float *rgb) {
+    shade_body<PRIMARY>(sc, fc, ws, stage, depth, spawn, rgb, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Shading of recursion level `depth` and compaction of the closest hits of level depth + 1 in one launch: the two are
+// independent (the compaction reads the geometry of the reflection rays, the shading writes their throughput), and each
+// is short enough that what a launch costs beside its work shows.
+template <bool PRIMARY>
+__global__ __launch_bounds__(256) void shade_compact_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth, int spawn_next,
+                                                            int list_misses, float *rgb, int compact_blocks) {
+    if ((int)blockIdx.x < compact_blocks)
+        compact_body<false, 2>(sc, fc, ws, stage + 1, depth + 1, spawn_next, list_misses, rgb, nullptr, nullptr, 0, (int)blockIdx.x, compact_blocks);
+    else
+        shade_body<PRIMARY>(sc, fc, ws, stage, depth, /*spawn=*/1, rgb, (int)blockIdx.x - compact_blocks, (int)gridDim.x - compact_blocks);
 }
 
 // Start of a pass: zero the counters the pass counts up from (`zero16` 16-byte words from `zero`), and fill the
@@ -1772,6 +1948,15 @@ void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc
         else
             bin_fill_kernel<false><<<face_blocks, 256, 0, stream>>>(sc, fc, ws, num_tris);
     }
+    // lists staged through LDS tile by tile, where a tile's rows are eight consecutive image rows from a multiple of eight
+    static const int tiled = getenv("RTAMD_RASTER_TILE") ? atoi(getenv("RTAMD_RASTER_TILE")) : 0; // experiment hook
+    if (tiled && (fc.num_parts == 1 || (fc.row_tile & 7) == 0)) {
+        if (count)
+            raster_tile_kernel<true><<<(total_static + 255) / 256, 256, 0, stream>>>(sc, fc, ws, total_static);
+        else
+            raster_tile_kernel<false><<<(total_static + 255) / 256, 256, 0, stream>>>(sc, fc, ws, total_static);
+        return;
+    }
     if (count)
         raster_kernel<true><<<(total_static + 255) / 256, 256, 0, stream>>>(sc, fc, ws, total_static);
     else
@@ -1886,6 +2071,48 @@ void launch_shade(bool primary, const DeviceScene &sc, const FrameConst &fc, con
         shade_kernel<true><<<sblocks, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, rgb);
     else
         shade_kernel<false><<<sblocks, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, rgb);
+}
+
+namespace {
+int bounce_walk_blocks(const Workspace &ws, int expect) {
+    long long groups = ws.capacity / 64;
+    if (expect >= 0) groups = std::min(groups, (with_margin(expect) + (ws.full_waves ? 63 : 15)) / (ws.full_waves ? 64 : 16));
+    return walk_grid(groups);
+}
+int shadow_blocks(const DeviceScene &sc, const FrameConst &fc, int expect) {
+    const int nshadow = sc.num_lights * sc.spl;
+    long long groups = (long long)(fc.tiles_x * fc.tiles_y) * nshadow;
+    if (expect >= 0) { // small launches put sixteen lanes on a ray: four hits per group
+        const long long hits = with_margin(expect);
+        const bool split = sc.use_grids && hits * nshadow < RT_SHADOW_SPLIT_BELOW;
+        groups = std::min(groups, (split ? (hits + 3) / 4 : (hits + 63) / 64) * nshadow);
+    }
+    return walk_grid(groups);
+}
+} // namespace
+
+bool can_fuse_shadow_walk(const DeviceScene &sc, const FrameConst &fc) { return sc.use_grids && sc.num_lights * sc.spl > 0 && fc.t_eps >= 0.0f; }
+bool can_fuse_shade_compact(const Workspace &ws) { return ws.capacity <= (4 << 20); }
+
+void launch_shadow_walk(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, int expect_hits,
+                        int expect_next, hipStream_t stream) {
+    const int wblocks = bounce_walk_blocks(ws, expect_next), sblocks = shadow_blocks(sc, fc, expect_hits);
+    if (count)
+        shadow_walk_kernel<true><<<wblocks + sblocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, wblocks);
+    else
+        shadow_walk_kernel<false><<<wblocks + sblocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, wblocks);
+}
+
+void launch_shade_compact(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, bool spawn_next,
+                          bool list_misses, float *rgb, int expect_hits, int expect_next, hipStream_t stream) {
+    long long slots = ws.capacity, hits = ws.capacity;
+    if (expect_next >= 0) slots = std::min(slots, with_margin(expect_next));
+    if (expect_hits >= 0) hits = std::min(hits, with_margin(expect_hits));
+    const int cblocks = (int)((slots + 511) / 512), sblocks = (int)((hits + 255) / 256);
+    if (primary)
+        shade_compact_kernel<true><<<cblocks + sblocks, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn_next, list_misses, rgb, cblocks);
+    else
+        shade_compact_kernel<false><<<cblocks + sblocks, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn_next, list_misses, rgb, cblocks);
 }
 
 void launch_misses(const FrameConst &fc, const Workspace &ws, int stage, int depth, float *rgb, int expect, hipStream_t stream) {
