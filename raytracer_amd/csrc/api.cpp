@@ -62,6 +62,7 @@ struct TimedLaunch {
 };
 
 constexpr int kMaxFrameSlots = 16;
+constexpr int kMaxHugeFaceList = 192; // kMaxHugeFaces of kernels.hip: entries of the list the compaction kernel tests against every pixel
 // Page-locked report block of a frame slot: [0..3] what the screen binning found, [kStageFeedbackAt + 2 * stage + {0, 1}]
 // hits and spawned rays of every stage, each + 1 (0: not reported yet).
 constexpr int kStageFeedbackAt = 16;
@@ -77,6 +78,7 @@ struct FrameSlot {
     bool used = false;            // `done` has been recorded at least once
     uint64_t stamp = 0;           // scene clock at the most recent frame
     bool binned = false;          // the most recent frame ran the screen-bin passes
+    bool rastered = false;        // ... or resolved its primary rays face by face
     // What the binning passes of earlier frames on this slot reported (pinned host memory the kernels write):
     // while it says that the lists were too long, the next frames of the same view walk the tree right away.
     volatile int32_t *feedback = nullptr;
@@ -91,6 +93,7 @@ struct rtamd_scene {
     int device = -1;
     int num_cus = 256;
     void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_materials = nullptr;
+    void *d_tri_of_rank = nullptr;
     void *d_light_pos = nullptr, *d_samples = nullptr, *d_spheres = nullptr, *d_texels = nullptr, *d_tex_info = nullptr;
     void *d_grid_headers = nullptr, *d_grid_cells = nullptr, *d_grid_entries = nullptr;
     DeviceScene ds{};
@@ -103,7 +106,8 @@ struct rtamd_scene {
     FrameSlot *last_frame_slot = nullptr; // slot of the most recent frame (what rtamd_render_stats reports)
     uint64_t clock = 0;
     rtamd_scene_info info{};
-    bool bin_primary = true; // screen binning of the primary rays (rtamd_build_params::primary_rays)
+    bool face_primary = true; // primary rays resolved face by face in screen space (rtamd_build_params::primary_rays AUTO)
+    bool bin_primary = false; // screen binning of the primary rays (RTAMD_PRIMARY_RAYS_BINS)
     bool bin_always = false; // ... also where the tree would be cheaper (RTAMD_PRIMARY_RAYS_BINS)
     std::vector<rtamd_material> materials;
     std::vector<int32_t> face_material;
@@ -138,7 +142,7 @@ int upload(void **dst, const std::vector<T> &src, uint64_t *bytes) {
 // Lays the work buffers of one frame in flight out behind `base` and returns the bytes they take; with base == nullptr
 // nothing is written through `ws` but sizes, so the same code answers "how much" and "where".
 // `slots` = ray slots of the local image = whole 8x8 tiles (a multiple of 64); bins == 0: no screen bins.
-size_t layout_workspace(char *base, size_t slots, size_t nshadow, size_t bins, size_t ntris, Workspace &ws) {
+size_t layout_workspace(char *base, size_t slots, size_t nshadow, size_t bins, size_t ntris, bool keys, Workspace &ws) {
     const size_t cap = (slots + 255) & ~(size_t)255; // every plane starts 1 KiB aligned
     const size_t head = 4096;                        // stage counters + work counters
     static_assert(sizeof(StageCounters) * kMaxStages <= 2048, "counter block too small");
@@ -153,10 +157,11 @@ size_t layout_workspace(char *base, size_t slots, size_t nshadow, size_t bins, s
     ws.stage = (StageCounters *)(uintptr_t)base;
     ws.work = (WorkCounters *)((uintptr_t)base + 2048);
     ws.bin_state = nullptr, ws.bin_count = nullptr, ws.bin_start = nullptr, ws.bin_entries = nullptr, ws.big = nullptr;
+    ws.pix_key = nullptr;
     ws.bin_capacity = 0;
-    if (bins) { // right behind the counters: one memset clears all three at the start of a frame
+    if (bins || keys) { // right behind the counters: one sweep clears all of them at the start of a frame
         ws.bin_state = (BinState *)take(256);
-        ws.bin_count = (int32_t *)take((bins + 256) * 4);
+        if (bins) ws.bin_count = (int32_t *)take((bins + 256) * 4);
         align(1024);
     }
     // tiles_x * 8 + tiles_y * 8 <= slots / 8 + 8 whatever the image's shape
@@ -173,9 +178,15 @@ size_t layout_workspace(char *base, size_t slots, size_t nshadow, size_t bins, s
     }
     for (float *&q : ws.queue) q = (float *)take(10 * cap * 4);
     for (uint8_t *&c : ws.clear) c = (uint8_t *)take(nshadow * cap);
-    if (bins) {
+    if (keys) {
         align(256);
-        ws.big = (int4 *)take((ntris + 1) * 16);
+        ws.pix_key = (unsigned long long *)take(cap * 8);
+    }
+    if (bins || keys) {
+        align(256);
+        ws.big = (int4 *)take(((bins ? ntris : (size_t)kMaxHugeFaceList) + 1) * 16);
+    }
+    if (bins) {
         ws.bin_start = (int32_t *)take((bins + 256) * 4);
         ws.bin_entries = (int32_t *)take(bin_capacity * 4);
         ws.bin_capacity = (int32_t)bin_capacity;
@@ -185,7 +196,8 @@ size_t layout_workspace(char *base, size_t slots, size_t nshadow, size_t bins, s
 }
 
 int ensure_workspace(rtamd_scene *s, FrameSlot &fs, size_t slots, size_t bins_needed) {
-    if (fs.block && (size_t)fs.ws.capacity >= slots && fs.bins >= (s->bin_primary ? bins_needed : 0)) return RTAMD_OK;
+    if (fs.block && (size_t)fs.ws.capacity >= slots && fs.bins >= (s->bin_primary ? bins_needed : 0) && (fs.ws.pix_key != nullptr) == s->face_primary)
+        return RTAMD_OK;
     if (fs.block) {
         HIP_TRY(hipFree(fs.block)); // waits for the device: no frame still reads the old block
         fs.block = nullptr;
@@ -195,9 +207,9 @@ int ensure_workspace(rtamd_scene *s, FrameSlot &fs, size_t slots, size_t bins_ne
     const size_t bins = s->bin_primary ? bins_needed : 0; // sized for the whole image this workspace may see
     int32_t *const feedback = fs.ws.bin_feedback, *const stage_feedback = fs.ws.stage_feedback;
     Workspace sizes{};
-    const size_t total = layout_workspace(nullptr, slots, nshadow, bins, ntris, sizes);
+    const size_t total = layout_workspace(nullptr, slots, nshadow, bins, ntris, s->face_primary, sizes);
     HIP_TRY(hipMalloc(&fs.block, total));
-    layout_workspace((char *)fs.block, slots, nshadow, bins, ntris, fs.ws);
+    layout_workspace((char *)fs.block, slots, nshadow, bins, ntris, s->face_primary, fs.ws);
     fs.ws.bin_feedback = feedback;
     fs.ws.stage_feedback = stage_feedback;
     fs.bins = bins;
@@ -480,6 +492,12 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     if (rc == RTAMD_OK) rc = upload(&s->d_nodes, bvh.nodes4, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_tris, bvh.tris, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_shade, shade, &bytes);
+    std::vector<int32_t> tri_of_rank((size_t)d->num_faces, -1); // face raster: the pixel keeps a rank, the shading wants the record
+    for (int32_t i = 0; i < num_records; ++i) {
+        const int32_t r = bvh.tris[(size_t)i].rank;
+        if (r >= 0 && r < d->num_faces) tri_of_rank[(size_t)r] = i;
+    }
+    if (rc == RTAMD_OK) rc = upload(&s->d_tri_of_rank, tri_of_rank, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_materials, mats, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_light_pos, lpos, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_samples, samples, &bytes);
@@ -520,6 +538,7 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     s->ds.light_pos = (const float *)s->d_light_pos;
     s->ds.samples = (const float *)s->d_samples;
     s->ds.spheres = (const float4 *)s->d_spheres;
+    s->ds.tri_of_rank = (const int32_t *)s->d_tri_of_rank;
     s->ds.texels = (const float *)s->d_texels;
     s->ds.tex_info = (const int32_t *)s->d_tex_info;
     s->ds.num_textures = textured ? d->num_textures : 0;
@@ -533,8 +552,11 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
         for (int gk = 0; gk < 4; ++gk) // a leaf directly under the root goes to one lane
             s->ds.start16[4 * ci + gk] = c >= 0 ? bvh.nodes4[(size_t)c].child[gk] : (gk == 0 ? c : 0x7fffffff);
     }
-    s->bin_primary = !(build && build->primary_rays == RTAMD_PRIMARY_RAYS_TREE);
-    s->bin_always = build && build->primary_rays == RTAMD_PRIMARY_RAYS_BINS;
+    static const bool faces_off = getenv("RTAMD_PRIMARY_FACES") && atoi(getenv("RTAMD_PRIMARY_FACES")) == 0; // experiment hook: AUTO bins as it used to
+    const int primary_mode = build ? build->primary_rays : RTAMD_PRIMARY_RAYS_AUTO;
+    s->face_primary = primary_mode == RTAMD_PRIMARY_RAYS_AUTO && !faces_off;
+    s->bin_primary = primary_mode == RTAMD_PRIMARY_RAYS_BINS || (primary_mode == RTAMD_PRIMARY_RAYS_AUTO && faces_off);
+    s->bin_always = primary_mode == RTAMD_PRIMARY_RAYS_BINS;
     s->info.shadow_grid_entries = !grids_usable ? 0 : grids_on_device ? dgrids.num_entries : (uint64_t)grids.entries.size();
     s->ds.num_lights = d->num_lights;
     s->ds.spl = d->samples_per_light;
@@ -573,7 +595,7 @@ int rtamd_reference_face_rank(const rtamd_scene_desc *d, int32_t *rank_out) {
 
 int rtamd_scene_destroy(rtamd_scene *s) {
     if (!s) return RTAMD_OK;
-    void *bufs[] = {s->d_nodes, s->d_tris,  s->d_shade,  s->d_materials, s->d_light_pos, s->d_samples,
+    void *bufs[] = {s->d_tri_of_rank, s->d_nodes, s->d_tris,  s->d_shade,  s->d_materials, s->d_light_pos, s->d_samples,
                     s->d_spheres, s->d_texels, s->d_tex_info, s->d_grid_headers, s->d_grid_cells, s->d_grid_entries,
                     s->d_rgb, s->d_face};
     (void)hipDeviceSynchronize(); // frames may still be in flight on the caller's streams
@@ -649,6 +671,7 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
     fc.tiles_x = tiles_x, fc.tiles_y = tiles_y;
     fc.row_tile = p->row_tile, fc.num_parts = p->num_parts, fc.part = p->part;
     fc.tiles_x_magic = tiles_x == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint64_t)tiles_x);
+    fc.num_parts_magic = p->num_parts == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint64_t)p->num_parts);
     fc.row_tile_magic = p->row_tile == 1 ? 0xffffffffu : (uint32_t)(0x100000000ull / (uint64_t)p->row_tile);
     fc.t_eps = p->t_epsilon, fc.refl_thresh = p->reflect_threshold, fc.bounce_off = p->bounce_offset;
     std::memcpy(fc.bg, p->background, sizeof fc.bg);
@@ -662,6 +685,11 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
     bool bins_kept_before = false;
     bool bins_ok = s->bin_primary && fs.ws.bin_entries != nullptr && bins_x < 32768 && bins_y < 32768 &&
                    (s->bin_always || (double)s->info.num_device_faces <= faces_per_pixel_max * (double)pixels);
+    // Face by face, the pass costs a projection per face and a test per pixel of each face's box; the tree walk costs some
+    // twenty-five node visits per pixel.  Past eight faces per rendered pixel the projections alone outweigh the walk.
+    static const double faces_per_pixel_raster = getenv("RTAMD_RASTER_FACES_PER_PIXEL") ? atof(getenv("RTAMD_RASTER_FACES_PER_PIXEL")) : 8.0;
+    bool faces_ok = s->face_primary && fs.ws.pix_key != nullptr && p->width < 65536 && p->height < 65536 && p->t_epsilon >= 0.0f &&
+                    (double)s->info.num_device_faces <= faces_per_pixel_raster * (double)pixels;
     // What earlier frames on this slot reported (page-locked memory their kernels wrote; a frame still in flight may be
     // half-way through updating it, which is harmless: the figures only pick launch sizes and the cheaper of two
     // equivalent paths).  Stage counts carry over between frames of one image size, partition and pass structure; the
@@ -686,7 +714,7 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
             expect_next[(size_t)i] = fs.feedback[kStageFeedbackAt + 2 * i + 1] - 1;
         }
     }
-    if (bins_ok && fs.feedback && !s->bin_always) {
+    if ((bins_ok || faces_ok) && fs.feedback && !s->bin_always) {
         if (fs.view_key != view_key) { // another view: what earlier passes reported says nothing about it
             fs.view_key = view_key;
             fs.feedback[0] = fs.feedback[1] = fs.feedback[2] = fs.feedback[3] = 0;
@@ -695,19 +723,19 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
         const bool turned_down = fs.feedback[3] != 0 && fs.feedback[2] != 0; // [2]: the pass's own verdict (bins_accepted)
         bins_kept_before = fs.feedback[3] != 0 && !turned_down;
         if (turned_down && fs.frames_without_bins < 63) { // try the bins again every 64th frame: the camera may have moved
-            bins_ok = false;
+            bins_ok = faces_ok = false;
             ++fs.frames_without_bins;
         } else {
             fs.frames_without_bins = 0;
         }
     }
-    if (bins_ok) {
+    if (bins_ok || faces_ok) {
         const float *m = cam->inv_view;
         const double a = m[0], b = m[1], c = m[2], d0 = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
         const double c00 = e * i - f * h, c01 = f * g - d0 * i, c02 = d0 * h - e * g;
         const double det = a * c00 + b * c01 + c * c02;
         if (!(std::fabs(det) > 1e-30) || !std::isfinite(det)) {
-            bins_ok = false;
+            bins_ok = faces_ok = false;
         } else {
             const double r = 1.0 / det;
             const double inv[9] = {c00 * r, (c * h - b * i) * r, (b * f - c * e) * r, c01 * r, (a * i - c * g) * r,
@@ -715,17 +743,19 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
             const double dt[3] = {(double)m[3] - cam->origin[0], (double)m[7] - cam->origin[1], (double)m[11] - cam->origin[2]};
             for (int k = 0; k < 9; ++k) fc.lin_inv[k] = (float)inv[k];
             for (int k = 0; k < 3; ++k) fc.cam_e[k] = (float)(inv[3 * k] * dt[0] + inv[3 * k + 1] * dt[1] + inv[3 * k + 2] * dt[2]);
-            if (!(std::fabs(fc.cam_e[2] - 1.0f) > 1e-6f)) bins_ok = false;
+            if (!(std::fabs(fc.cam_e[2] - 1.0f) > 1e-6f)) bins_ok = faces_ok = false;
         }
         fc.bins_x = bins_x, fc.bins_y = bins_y;
     }
     fs.ws.dir_y = fs.ws.dir_x + tiles_x * 8;
     Workspace ws_frame = fs.ws; // what the kernels of this frame see
     if (!bins_ok) ws_frame.bin_entries = nullptr;
+    if (!faces_ok) ws_frame.pix_key = nullptr;
     fs.binned = bins_ok;
+    fs.rastered = faces_ok;
     ws_frame.bin_max_list = s->bin_always ? 0x7fffffff : kMaxAverageBinList;
     ws_frame.num_bins = bins_x * bins_y;
-    ws_frame.bins_expected = bins_ok && bins_kept_before;
+    ws_frame.bins_expected = (bins_ok || faces_ok) && bins_kept_before;
     static const int forced_waves = getenv("RTAMD_FULL_WAVES") ? atoi(getenv("RTAMD_FULL_WAVES")) : -1; // experiment hook
     ws_frame.full_waves = forced_waves >= 0 ? forced_waves : s->num_slots > 1; // several caller streams: frames overlap
 
@@ -770,7 +800,8 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
 
     // Every pass starts with prep_kernel: it fills the pass's screen-coordinate tables and zeroes the bin counters; the first
     // one also zeroes the stage and work counters of the frame, which lie right in front of them.
-    const size_t bin_clear = bins_ok ? ((256 + sizeof(int32_t) * (size_t)ws_frame.num_bins + 15) & ~(size_t)15) : 0;
+    const size_t bin_clear = bins_ok ? ((256 + sizeof(int32_t) * (size_t)ws_frame.num_bins + 15) & ~(size_t)15) : faces_ok ? 256 : 0;
+    const size_t key_clear = faces_ok ? pixels * sizeof(unsigned long long) : 0; // (the keys are indexed by local row and column)
     int stage = 0;
     for (int xs = 0; xs < S; ++xs)
         for (int ys = 0; ys < S; ++ys) {
@@ -778,9 +809,9 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
             fc.sub_y = (float)ys / S;
             fc.accumulate = (xs | ys) != 0;
             if (stage == 0)
-                launch_prep(fc, ws_frame, fs.block, 4096 + bin_clear, stream);
+                launch_prep(fc, ws_frame, fs.block, 4096 + bin_clear, ws_frame.pix_key, key_clear, stream);
             else
-                launch_prep(fc, ws_frame, (char *)fs.block + 4096, bin_clear, stream);
+                launch_prep(fc, ws_frame, (char *)fs.block + 4096, bin_clear, ws_frame.pix_key, key_clear, stream);
             // Fused form: the shadow rays of level d share a launch with the closest hits of level d + 1, and the shading of
             // level d with the compaction of level d + 1 (each pair needs only what the launch before it produced), all on
             // the caller's stream.  The GPU runs only a few kernels at a time however many streams feed it, so what a frame
@@ -790,9 +821,10 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
             for (int d = 0; fuse && d < depths; ++d, ++stage) {
                 const bool spawn = d + 1 < depths;
                 if (d == 0) {
+                    if (faces_ok) launch_primary_faces(count, s->ds, fc, ws_frame, s->info.num_device_faces, stream);
                     if (bins_ok) launch_primary_bins(count, s->ds, fc, ws_frame, s->info.num_device_faces, /*cleared=*/true, stream);
-                    // the tree walk behind the bins runs only where the pass turns its bins down; the same view kept them before
-                    if (!(bins_ok && ws_frame.bins_expected)) launch_walk_closest(true, count, s->ds, fc, ws_frame, stage, 0, -1, stream);
+                    // the tree walk behind them runs only where the pass gives way to it; the same view did not before
+                    if (!ws_frame.bins_expected) launch_walk_closest(true, count, s->ds, fc, ws_frame, stage, 0, -1, stream);
                     launch_compact(true, s->ds, fc, ws_frame, stage, 0, spawn, false, rgb, face_id, t_hit, -1, stream);
                 }
                 const int hits_here = expect_hits[(size_t)stage], rays_next = expect_next[(size_t)stage];
@@ -813,7 +845,8 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
             for (int d = 0; !fuse && d < depths; ++d, ++stage) {
                 const bool spawn = d + 1 < depths;
                 // ---- closest hits
-                if ((rc = begin(d == 0 && bins_ok ? 6 : 0)) != RTAMD_OK) return rc;
+                if ((rc = begin(d == 0 && (bins_ok || faces_ok) ? 6 : 0)) != RTAMD_OK) return rc;
+                if (d == 0 && faces_ok) launch_primary_faces(count, s->ds, fc, ws_frame, s->info.num_device_faces, stream);
                 if (d == 0 && bins_ok) launch_primary_bins(count, s->ds, fc, ws_frame, s->info.num_device_faces, /*cleared=*/true, stream);
                 launch_walk_closest(d == 0, count, s->ds, fc, ws_frame, stage, d, d > 0 ? expect_next[(size_t)stage - 1] : -1, stream); // after the bins: only on their overflow
                 if ((rc = end()) != RTAMD_OK) return rc;
@@ -894,15 +927,17 @@ int rtamd_render_device_noalloc(rtamd_scene *s, const rtamd_camera *cam, const r
     const size_t ntris = (size_t)s->info.num_device_faces;
     const size_t bins = s->bin_primary ? (size_t)shape.bins_x * (size_t)shape.bins_y : 0;
     Workspace sizes{};
-    const size_t need_plain = layout_workspace(nullptr, shape.slots, shape.nshadow, 0, ntris, sizes);
+    const size_t need_plain = layout_workspace(nullptr, shape.slots, shape.nshadow, 0, ntris, false, sizes);
     if (need_plain > kScratchBytes)
         return fail(RTAMD_ERR_LIMIT, "a frame of %d x %d pixels with %zu shadow rays per hit needs %zu bytes of work buffers; "
                     "rtamd_render_device_noalloc holds %zu (use rtamd_render_device)", p->width, shape.local_rows, shape.nshadow, need_plain, kScratchBytes);
-    const bool with_bins = bins > 0 && layout_workspace(nullptr, shape.slots, shape.nshadow, bins, ntris, sizes) <= kScratchBytes;
+    // the buffers of the screen-space pass for the primary rays (per-pixel keys, or bins) only when they fit as well
+    const bool with_keys = s->face_primary && layout_workspace(nullptr, shape.slots, shape.nshadow, 0, ntris, true, sizes) <= kScratchBytes;
+    const bool with_bins = bins > 0 && layout_workspace(nullptr, shape.slots, shape.nshadow, bins, ntris, false, sizes) <= kScratchBytes;
     char *base = s->scratch; // looked up when the scene was created
     if (!base && (rc = scratch_pointer(dev, &base)) != RTAMD_OK) return rc;
     FrameSlot &fs = s->static_slot;
-    layout_workspace(base, shape.slots, shape.nshadow, with_bins ? bins : 0, ntris, fs.ws);
+    layout_workspace(base, shape.slots, shape.nshadow, with_bins ? bins : 0, ntris, with_keys, fs.ws);
     fs.block = base;
     fs.bins = with_bins ? bins : 0;
     fs.stream = (hipStream_t)hip_stream;
@@ -933,6 +968,11 @@ int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
         st->box_tests[k] = wc[k].box_tests;
         st->tri_plane[k] = wc[k].tri_plane;
         st->tri_edge[k] = wc[k].tri_edge;
+    }
+    if (s->last_frame_slot->rastered) {
+        BinState bs;
+        HIP_TRY(hipMemcpy(&bs, ws_last.bin_state, sizeof bs, hipMemcpyDeviceToHost));
+        st->primary_path = !bs.fallback && bs.num_big <= kMaxHugeFaceList ? 1 : 0;
     }
     if (s->last_frame_slot->binned) {
         BinState bs;

@@ -21,6 +21,7 @@ struct DeviceScene {
     const float *light_pos;   // 3 per light
     const float *samples;     // 3 per (light, sample)
     const float4 *spheres;    // center, radius
+    const int32_t *tri_of_rank; // record index of the face with a given rank (position in the reference's visiting order), -1 = none
     int32_t num_lights, spl, num_spheres, num_materials;
     int32_t num_textures; // 0 also when the mesh has no texture coordinates
     // shadow-ray candidate grids (shadow_grid.hpp), one per light sample; use_grids = 0: shadow rays walk the tree
@@ -43,6 +44,7 @@ struct FrameConst {
     int32_t width, height, local_rows;
     int32_t tiles_x, tiles_y; // 8x8-pixel tiles of the local image
     int32_t row_tile, num_parts, part;
+    uint32_t num_parts_magic; // floor(2^32 / num_parts), likewise
     uint32_t tiles_x_magic, row_tile_magic; // floor(2^32 / tiles_x), floor(2^32 / row_tile) (0xffffffff for 1): fast_div in kernels.hip
     float t_eps, refl_thresh, bounce_off;
     float bg[3], bg_deep[3];
@@ -108,6 +110,9 @@ struct Workspace {
     float *dir_x, *dir_y;
     StageCounters *stage; // kMaxStages
     WorkCounters *work;   // [0] closest-hit walk, [1] shadow kernel, [2] screen-bin raster
+    // Primary rays resolved face by face (face_raster_kernel): per pixel of the local image, the complement of (distance
+    // bits, inverted rank) of the best face so far, zero = none; nullptr: not in use for this frame
+    unsigned long long *pix_key;
     // screen binning of the primary rays; bin_entries == nullptr: not in use
     BinState *bin_state;
     int32_t *bin_count;   // per bin: faces whose projection touches it; then the fill cursor

@@ -171,6 +171,14 @@ __device__ __forceinline__ bool bins_accepted(const Workspace &ws) {
            (long long)st->total <= (long long)ws.bin_max_list * (long long)max(st->nonempty, 1);
 }
 
+constexpr int kMaxHugeFaces = 192; // more faces than this in the per-pixel list: the tree walk takes the pass
+
+// Face raster of this pass usable?  Known after face_raster_kernel.
+__device__ __forceinline__ bool keys_accepted(const Workspace &ws) {
+    const BinState *st = ws.bin_state;
+    return !st->fallback && st->num_big <= kMaxHugeFaces;
+}
+
 __device__ __forceinline__ void flush_work(unsigned a, unsigned b, unsigned c, WorkCounters *out) {
     for (int off = 32; off > 0; off >>= 1) {
         a += __shfl_xor(a, off);
@@ -267,6 +275,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
     int *const leafq = s_stack + kLdsStack * 64 + lane;
     constexpr int CAP = MODE == kShadow ? kLeafQueue : kLeafQueueClosest;
 
+    if (MODE == kPrimary && ws.pix_key && keys_accepted(ws)) return;         // face_raster_kernel did this pass
     if (MODE == kPrimary && ws.bin_entries && bins_accepted(ws)) return; // raster_kernel does this pass
     const int nshadow = sc.num_lights * sc.spl;
     int rays, nhits = 0;
@@ -611,6 +620,7 @@ __device__ __forceinline__ void walk_steal_body(const DeviceScene &sc, const Fra
     constexpr int CAP = kLeafQueueClosest;
     const unsigned long long below = (1ull << lane) - 1ull;
 
+    if (MODE == kPrimary && ws.pix_key && keys_accepted(ws)) return;         // face_raster_kernel did this pass
     if (MODE == kPrimary && ws.bin_entries && bins_accepted(ws)) return; // raster_kernel does this pass
     const int rays = MODE == kPrimary ? total_static : ws.stage[stage - 1].next;
     int shift = 6;
@@ -876,43 +886,66 @@ __device__ __forceinline__ bool project_point(const FrameConst &fc, V3 p, float 
     return px == px && py == py;
 }
 
-__device__ __forceinline__ PixelBox face_bins(const DeviceScene &sc, const FrameConst &fc, int tri) {
-    PixelBox b;
-    b.empty = false, b.big = false, b.cull = false;
+// Projection of one face: the integer pixels [px0, px1] x [py0, py1] (clamped to the image) whose sample points can
+// lie inside the projected triangle widened by the margin, and the projected corners themselves.
+struct ProjectedFace {
+    bool empty;     // no pixel of the image can see the face
+    bool unbounded; // a corner beside or behind the eye: the box is the whole image
+    float x0, y0, x1, y1, x2, y2;
+    int px0, py0, px1, py1;
+};
+__device__ __forceinline__ ProjectedFace project_face(const DeviceScene &sc, const FrameConst &fc, int tri) {
+    ProjectedFace f;
+    f.empty = false, f.unbounded = false;
+    f.x0 = f.y0 = f.x1 = f.y1 = f.x2 = f.y2 = 0.0f;
+    f.px0 = f.py0 = 0, f.px1 = f.py1 = -1;
     const float4 p0 = sc.tris[tri * 4 + 1], p1 = sc.tris[tri * 4 + 2], p2 = sc.tris[tri * 4 + 3];
-    float x0 = 0, y0 = 0, x1 = 0, y1 = 0, x2 = 0, y2 = 0;
     bool back0, back1, back2;
-    const bool ok0 = project_point(fc, mk(p0.x, p0.y, p0.z), x0, y0, back0);
-    const bool ok1 = project_point(fc, mk(p1.x, p1.y, p1.z), x1, y1, back1);
-    const bool ok2 = project_point(fc, mk(p2.x, p2.y, p2.z), x2, y2, back2);
-    const bool ok = ok0 && ok1 && ok2;
+    const bool ok0 = project_point(fc, mk(p0.x, p0.y, p0.z), f.x0, f.y0, back0);
+    const bool ok1 = project_point(fc, mk(p1.x, p1.y, p1.z), f.x1, f.y1, back1);
+    const bool ok2 = project_point(fc, mk(p2.x, p2.y, p2.z), f.x2, f.y2, back2);
     // Every point a primary ray reaches at a positive distance lies in front of the eye plane (s > 0 above, and s is
     // linear in the point); a face with all three corners clearly behind that plane lies behind it entirely and can
     // meet no such ray.  Without this, a view from inside or past the mesh sent those faces to the list every pixel scans.
     if (back0 && back1 && back2) {
-        b.empty = true;
-        b.x0 = b.y0 = 0, b.x1 = b.y1 = -1;
-        return b;
+        f.empty = true;
+        return f;
     }
     float xlo = 0.0f, ylo = 0.0f, xhi = (float)fc.width, yhi = (float)fc.height;
-    if (ok) {
+    if (ok0 && ok1 && ok2) {
         // pixel (x, y) samples at (x + sub_x, y + sub_y): shift the box instead of the samples; the margin covers
         // the rounding of the projection (about 1e-3 pixel at 8K) and of the exact test many times over
         const float margin = kBinMargin;
-        xlo = fminf(fminf(x0, x1), x2) - margin - fc.sub_x, xhi = fmaxf(fmaxf(x0, x1), x2) + margin - fc.sub_x;
-        ylo = fminf(fminf(y0, y1), y2) - margin - fc.sub_y, yhi = fmaxf(fmaxf(y0, y1), y2) + margin - fc.sub_y;
+        xlo = fminf(fminf(f.x0, f.x1), f.x2) - margin - fc.sub_x, xhi = fmaxf(fmaxf(f.x0, f.x1), f.x2) + margin - fc.sub_x;
+        ylo = fminf(fminf(f.y0, f.y1), f.y2) - margin - fc.sub_y, yhi = fmaxf(fmaxf(f.y0, f.y1), f.y2) + margin - fc.sub_y;
     } else {
-        b.big = true; // a vertex beside or behind the eye: its projection is unbounded
+        f.unbounded = true;
     }
     // integer pixels inside [lo, hi]
     const float fx0 = fmaxf(ceilf(xlo), 0.0f), fy0 = fmaxf(ceilf(ylo), 0.0f);
     const float fx1 = fminf(floorf(xhi), (float)(fc.width - 1)), fy1 = fminf(floorf(yhi), (float)(fc.height - 1));
     if (!(fx0 <= fx1 && fy0 <= fy1)) {
+        f.empty = true;
+        return f;
+    }
+    f.px0 = (int)fx0, f.py0 = (int)fy0, f.px1 = (int)fx1, f.py1 = (int)fy1;
+    return f;
+}
+
+__device__ __forceinline__ PixelBox face_bins(const DeviceScene &sc, const FrameConst &fc, int tri) {
+    PixelBox b;
+    b.empty = false, b.big = false, b.cull = false;
+    const ProjectedFace pf = project_face(sc, fc, tri);
+    if (pf.empty) {
         b.empty = true;
         b.x0 = b.y0 = 0, b.x1 = b.y1 = -1;
         return b;
     }
-    b.x0 = (int)fx0 / kBinPixels, b.x1 = (int)fx1 / kBinPixels, b.y0 = (int)fy0 / kBinPixels, b.y1 = (int)fy1 / kBinPixels;
+    const bool ok = !pf.unbounded;
+    if (!ok) b.big = true; // a vertex beside or behind the eye: its projection is unbounded
+    const float x0 = pf.x0, y0 = pf.y0, x1 = pf.x1, y1 = pf.y1, x2 = pf.x2, y2 = pf.y2;
+    const int fx0 = pf.px0, fy0 = pf.py0, fx1 = pf.px1, fy1 = pf.py1;
+    b.x0 = fx0 / kBinPixels, b.x1 = fx1 / kBinPixels, b.y0 = fy0 / kBinPixels, b.y1 = fy1 / kBinPixels;
     if ((b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1) > kBigBins) b.big = true;
     // The box of a triangle holds about twice the bins the triangle touches.  Worth three edge evaluations per bin
     // once the box spans 2 x 2 bins; only with all vertices near the screen (the edge functions are products of pixel
@@ -1111,6 +1144,138 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(DeviceScene sc, FrameCons
             ws.bin_entries[ws.bin_start[bin] + atomicAdd(&ws.bin_count[bin], 1)] = tri;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Primary rays, face by face.  The pixel-by-pixel pass above makes every pixel of a bin run through all faces that
+// touch the bin -- a dozen exact tests per pixel where a face covers two or three pixels, and as long as the longest
+// list for the launch as a whole.  Turned around, every face is tested against the pixels of its own projected box
+// only (six pairs per face on the 1080p bunny, a sixth of the tests) and the pixels keep the best candidate through
+// one 64-bit atomic maximum per accepted pair: the complement of (distance bits, inverted rank), so that zero means
+// "nothing yet", the nearest face wins and equal distances go to the face the reference meets later
+// (src/flyscene.cpp:760).  No bins, no lists, no second pass over the faces.
+// A wave takes 64 faces.  Where all their boxes are tiny (a distant or finely tessellated mesh) every lane steps through
+// its own face's pixels; otherwise the wave's (face, pixel) pairs are numbered consecutively and dealt to the lanes 64
+// at a time, whatever the sizes of the boxes, with the faces' records staged in LDS.  Faces whose box exceeds
+// kHugePixels (or is unbounded: a corner beside or behind the eye) go to the list that the compaction kernel tests
+// against every pixel; when that list grows long (the eye inside a dense mesh) the pass gives way to the tree walk.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHugePixels = 16384; // a face with a larger pixel box is tested pixel by pixel in the compaction kernel
+constexpr int kDirectPairs = 8;    // waves whose faces all have at most this many pixels skip the dealing
+
+// Local (packed) row of image row gy under the row-tile partition; false: another part renders that row.
+__device__ __forceinline__ bool local_row_of(const FrameConst &fc, int gy, int &lr) {
+    if (fc.num_parts == 1) {
+        lr = gy;
+        return true;
+    }
+    const int tile = (int)fast_div((unsigned)gy, (unsigned)fc.row_tile, fc.row_tile_magic);
+    const int lt = (int)fast_div((unsigned)tile, (unsigned)fc.num_parts, fc.num_parts_magic);
+    if (tile - lt * fc.num_parts != fc.part) return false;
+    lr = lt * fc.row_tile + (gy - tile * fc.row_tile);
+    return true;
+}
+
+// One (face, pixel) pair: the exact plane + three-edge test of src/flyscene.cpp:752-789 for the pixel's primary ray.
+template <bool COUNT>
+__device__ __forceinline__ void raster_pair(const FrameConst &fc, const Workspace &ws, float4 pn, float4 r0, float4 r1, float4 r2, int x, int gy,
+                                            unsigned &w_plane, unsigned &w_edge) {
+    int lr;
+    if (!local_row_of(fc, gy, lr)) return;
+    const V3 o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
+    const V3 d = primary_direction(fc, ws, x, lr);
+    unsigned long long *const cell = ws.pix_key + ((size_t)lr * (size_t)fc.width + (size_t)x);
+    if (COUNT) ++w_plane;
+    const V3 n = mk(pn.x, pn.y, pn.z);
+    const float t = (pn.w - dot(o, n)) / dot(d, n);
+    if (!(t >= fc.t_eps && t <= FLT_MAX)) return; // also rejects NaN (see file header)
+    // what the pixel holds already (possibly a moment ago: it only ever gets nearer) spares the edge tests of faces behind it
+    const unsigned long long seen = *cell;
+    if (seen != 0ull && t > __int_as_float((int)(unsigned)(~seen >> 32))) return;
+    if (COUNT) ++w_edge;
+    const V3 v0 = mk(r0.x, r0.y, r0.z), v1 = mk(r1.x, r1.y, r1.z), v2 = mk(r2.x, r2.y, r2.z);
+    const V3 hp = o + t * d;
+    if (dot(cross(v1 - v0, hp - v0), n) < 0) return;
+    if (dot(cross(v2 - v1, hp - v1), n) < 0) return;
+    if (dot(cross(v0 - v2, hp - v2), n) < 0) return;
+    atomicMax(cell, ~hit_key(t, __float_as_int(r1.w)));
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void face_raster_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int num_tris) {
+    __shared__ float4 s_rec[4][4][64]; // per wave: the four quarters of its faces' records
+    __shared__ int4 s_box[4][64];      // ... first pixel column and row, box width, floor(2^32 / width)
+    __shared__ int s_off[4][64];       // ... number of the face's first pair
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int tri = (int)(blockIdx.x * 256 + threadIdx.x);
+    unsigned w_box = 0, w_plane = 0, w_edge = 0;
+    ProjectedFace f;
+    f.empty = true, f.unbounded = false, f.px0 = f.py0 = 0, f.px1 = f.py1 = -1;
+    if (tri < num_tris) f = project_face(sc, fc, tri);
+    if (COUNT && tri < num_tris) ++w_box;
+    int w = f.px1 - f.px0 + 1, h = f.py1 - f.py0 + 1;
+    if (!f.empty && fc.num_parts > 1) { // rows of other parts only?  (a small face lies in one or two row tiles)
+        const int t0 = (int)fast_div((unsigned)f.py0, (unsigned)fc.row_tile, fc.row_tile_magic);
+        const int t1 = (int)fast_div((unsigned)f.py1, (unsigned)fc.row_tile, fc.row_tile_magic);
+        bool mine = t1 - t0 + 1 >= fc.num_parts;
+        for (int t = t0; !mine && t <= t1; ++t) {
+            const int lt = (int)fast_div((unsigned)t, (unsigned)fc.num_parts, fc.num_parts_magic);
+            mine = t - lt * fc.num_parts == fc.part;
+        }
+        if (!mine) f.empty = true;
+    }
+    const bool huge = !f.empty && (f.unbounded || w * h > kHugePixels);
+    if (huge) {
+        const int at = atomicAdd(&ws.bin_state->num_big, 1);
+        if (at < kMaxHugeFaces) ws.big[at] = make_int4(tri, f.px0 | (f.py0 << 16), f.px1 | (f.py1 << 16), 0);
+    }
+    const int count = (f.empty || huge) ? 0 : w * h;
+    int most = count;
+    for (int off = 32; off > 0; off >>= 1) most = max(most, __shfl_xor(most, off, 64));
+    if (most > 0) {
+        const float4 pn = sc.tris[(size_t)min(tri, num_tris - 1) * 4 + 0], r0 = sc.tris[(size_t)min(tri, num_tris - 1) * 4 + 1];
+        const float4 r1 = sc.tris[(size_t)min(tri, num_tris - 1) * 4 + 2], r2 = sc.tris[(size_t)min(tri, num_tris - 1) * 4 + 3];
+        if (most <= kDirectPairs) {
+            // every lane its own face: k-th pixel of the box, row by row
+            int x = f.px0, y = f.py0;
+            for (int k = 0; k < most; ++k) {
+                if (k < count) raster_pair<COUNT>(fc, ws, pn, r0, r1, r2, x, y, w_plane, w_edge);
+                if (++x > f.px1) x = f.px0, ++y;
+            }
+        } else {
+            s_rec[wave][0][lane] = pn, s_rec[wave][1][lane] = r0, s_rec[wave][2][lane] = r1, s_rec[wave][3][lane] = r2;
+            s_box[wave][lane] = make_int4(f.px0, f.py0, max(w, 1), (int)(w <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / (unsigned long long)w)));
+            int incl = count; // inclusive scan of the counts over the wave
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                const int up = __shfl_up(incl, dlt, 64);
+                if (lane >= dlt) incl += up;
+            }
+            const int total = __shfl(incl, 63, 64);
+            s_off[wave][lane] = incl - count;
+            wave_sync();
+            for (int j0 = 0; j0 < total; j0 += 64) {
+                const int j = j0 + lane;
+                if (j < total) {
+                    // the face of pair j: the last one whose first pair is <= j (faces without pixels share their successor's number)
+                    int lo = 0, hi = 63;
+#pragma unroll
+                    for (int step = 0; step < 6; ++step) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (s_off[wave][mid] <= j)
+                            lo = mid;
+                        else
+                            hi = mid - 1;
+                    }
+                    const int4 box = s_box[wave][lo];
+                    const unsigned k = (unsigned)(j - s_off[wave][lo]);
+                    const unsigned row = fast_div(k, (unsigned)box.z, (unsigned)box.w);
+                    raster_pair<COUNT>(fc, ws, s_rec[wave][0][lo], s_rec[wave][1][lo], s_rec[wave][2][lo], s_rec[wave][3][lo], box.x + (int)(k - row * (unsigned)box.z),
+                                       box.y + (int)row, w_plane, w_edge);
+                }
+            }
+        }
+    }
+    if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 2);
 }
 
 // Candidates per round trip in raster_kernel.  Two: 70 VGPRs and seven waves per SIMD; four take 84 and five waves,
@@ -1554,21 +1719,72 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
     const int total = PRIMARY ? total_static : ws.stage[stage - 1].next;
     const HitList hl = ws.hits[depth & 1];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool from_keys = PRIMARY && ws.pix_key != nullptr && keys_accepted(ws); // the pass was resolved face by face
+    if (PRIMARY && ws.pix_key != nullptr && block == 0 && tid == 0 && ws.bin_feedback) { // the pass's verdict, for the next frames of the view
+        ws.bin_feedback[0] = 0, ws.bin_feedback[1] = 0;
+        ws.bin_feedback[2] = from_keys ? 0 : 1, ws.bin_feedback[3] = 1;
+    }
     // the grid may be smaller than the work (it is sized from what earlier frames of the view needed): stride over it
     for (int first = block * (256 * kCompactSegments); first < total; first += nblocks * (256 * kCompactSegments)) {
 
     // ---- pass 1: classify the slots of every segment, count per wave
     int tri_of[kCompactSegments];
+    float t_of[kCompactSegments];
     unsigned hit_bits = 0, go_bits = 0, miss_bits = 0;
 #pragma unroll
     for (int j = 0; j < kCompactSegments; ++j) {
         const int slot = first + j * 256 + tid;
         bool valid = slot < total;
-        if (PRIMARY && valid) {
-            int x, row;
-            valid = slot_pixel(fc, slot, x, row);
+        int x = 0, row = 0;
+        if (PRIMARY && valid) valid = slot_pixel(fc, slot, x, row);
+        int tri = -2;
+        float t_found = 0.0f;
+        if (PRIMARY && from_keys) {
+            // What face_raster_kernel left in the pixel: complement of (distance bits, inverted rank); zero = no face.
+            // Then the faces too large for that kernel and the spheres, against this pixel's ray, under the same
+            // rule: nearest wins, equal distances go to the later face, a sphere loses a tie (intersects(), :673-676).
+            if (valid) {
+                float tbest = FLT_MAX;
+                int best_rank = -1;
+                const unsigned long long held = ws.pix_key[(size_t)row * (size_t)fc.width + (size_t)x];
+                if (held != 0ull) {
+                    tbest = __int_as_float((int)(unsigned)(~held >> 32));
+                    best_rank = 0x7fffffff - (int)(unsigned)(~held & 0xffffffffull);
+                    tri = sc.tri_of_rank[best_rank];
+                }
+                const int nbig = ws.bin_state->num_big;
+                if (nbig > 0 || sc.num_spheres > 0) {
+                    const V3 o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
+                    const V3 d = primary_direction(fc, ws, x, row);
+                    float ts = FLT_MAX;
+                    if (sc.num_spheres > 0 && spheres_hit(sc, o, d, fc.t_eps, ts) && ts < tbest) tbest = ts, tri = -1, best_rank = -1;
+                    const int gy = global_row(fc, row);
+                    for (int e = 0; e < nbig; ++e) {
+                        const int4 g = ws.big[e];
+                        if (x < (g.y & 0xffff) || x > (g.z & 0xffff) || gy < (g.y >> 16) || gy > (g.z >> 16)) continue;
+                        const float4 *rec = sc.tris + (size_t)g.x * 4;
+                        const float4 pn = rec[0];
+                        const V3 n = mk(pn.x, pn.y, pn.z);
+                        const float t = (pn.w - dot(o, n)) / dot(d, n);
+                        if (!(t >= fc.t_eps && t <= tbest)) continue; // also rejects NaN (see file header)
+                        const float4 r0 = rec[1], r1 = rec[2], r2 = rec[3];
+                        const int rank = __float_as_int(r1.w);
+                        if (t == tbest && rank < best_rank) continue; // equal distance: the later face wins (:760)
+                        const V3 v0 = mk(r0.x, r0.y, r0.z), v1 = mk(r1.x, r1.y, r1.z), v2 = mk(r2.x, r2.y, r2.z);
+                        const V3 hp = o + t * d;
+                        if (dot(cross(v1 - v0, hp - v0), n) < 0) continue;
+                        if (dot(cross(v2 - v1, hp - v1), n) < 0) continue;
+                        if (dot(cross(v0 - v2, hp - v2), n) < 0) continue;
+                        tbest = t, tri = g.x, best_rank = rank;
+                    }
+                }
+                t_found = tri != -2 ? tbest : 0.0f;
+            }
+        } else {
+            tri = valid ? ws.slot_tri[slot] : -2;
+            t_found = valid && tri != -2 ? ws.slot_t[slot] : 0.0f;
         }
-        const int tri = valid ? ws.slot_tri[slot] : -2;
+        t_of[j] = t_found;
         const bool hit = tri != -2;
         const bool miss = list_misses && valid && !hit;
         // does this hit reflect?  src/flyscene.cpp:617-632 (a sphere ends the path, :618-621)
@@ -1615,7 +1831,7 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
         }
         pos_hit += __popcll(m_hit & below), pos_go += __popcll(m_go & below), pos_miss += __popcll(m_miss & below);
 
-        const float t = hit ? ws.slot_t[slot] : 0.0f;
+        const float t = t_of[j];
         V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
         int pix = 0;
         if (PRIMARY) {
@@ -1835,9 +2051,10 @@ __global__ __launch_bounds__(256) void shade_compact_kernel(DeviceScene sc, Fram
 
 // Start of a pass: zero the counters the pass counts up from (`zero16` 16-byte words from `zero`), and fill the
 // tables of the pass's screen coordinates (primary_direction): dir_x per image column, dir_y per LOCAL row.
-__global__ __launch_bounds__(256) void prep_kernel(FrameConst fc, Workspace ws, int4 *zero, int zero16) {
+__global__ __launch_bounds__(256) void prep_kernel(FrameConst fc, Workspace ws, int4 *zero, int zero16, int4 *zero_b, int zero_b16) {
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
     for (int k = i; k < zero16; k += (int)gridDim.x * 256) zero[k] = make_int4(0, 0, 0, 0);
+    for (int k = i; k < zero_b16; k += (int)gridDim.x * 256) zero_b[k] = make_int4(0, 0, 0, 0);
     const int nx = fc.tiles_x * 8, ny = fc.tiles_y * 8;
     for (int k = i; k < nx + ny; k += (int)gridDim.x * 256) {
         if (k < nx)
@@ -1917,11 +2134,22 @@ int walk_grid(long long groups) {
 }
 } // namespace
 
-void launch_prep(const FrameConst &fc, const Workspace &ws, void *zero, size_t zero_bytes, hipStream_t stream) {
-    const int zero16 = (int)((zero_bytes + 15) / 16);
-    const int items = std::max(zero16, (fc.tiles_x + fc.tiles_y) * 8);
-    const int blocks = std::max(1, std::min(1024, (items + 255) / 256));
-    prep_kernel<<<blocks, 256, 0, stream>>>(fc, ws, (int4 *)zero, zero16);
+void launch_prep(const FrameConst &fc, const Workspace &ws, void *zero, size_t zero_bytes, void *zero_b, size_t zero_b_bytes, hipStream_t stream) {
+    const int zero16 = (int)((zero_bytes + 15) / 16), zero_b16 = (int)((zero_b_bytes + 15) / 16);
+    const int items = std::max(std::max(zero16, zero_b16), (fc.tiles_x + fc.tiles_y) * 8);
+    const int blocks = std::max(1, std::min(2048, (items + 255) / 256));
+    prep_kernel<<<blocks, 256, 0, stream>>>(fc, ws, (int4 *)zero, zero16, (int4 *)zero_b, zero_b16);
+}
+
+// Primary rays of one pass face by face (ws.pix_key must be set and zeroed): one launch.  The pixels are resolved by
+// launch_compact; the tree walk behind it (launch_walk_closest) only does anything where the pass gave way to it.
+void launch_primary_faces(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, hipStream_t stream) {
+    if (num_tris <= 0) return;
+    const unsigned blocks = (unsigned)((num_tris + 255) / 256);
+    if (count)
+        face_raster_kernel<true><<<blocks, 256, 0, stream>>>(sc, fc, ws, num_tris);
+    else
+        face_raster_kernel<false><<<blocks, 256, 0, stream>>>(sc, fc, ws, num_tris);
 }
 
 void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, bool cleared,
@@ -1980,7 +2208,7 @@ void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const 
     long long groups = primary ? fc.tiles_x * fc.tiles_y : ws.capacity / 64;
     if (!primary && expect >= 0) // narrow groups (a launch alone on the chip) hold as few as sixteen rays
         groups = std::min(groups, (with_margin(expect) + (ws.full_waves ? 63 : 15)) / (ws.full_waves ? 64 : 16));
-    const int blocks = primary && ws.bin_entries ? (ws.bins_expected ? 2048 : 16384) : walk_grid(groups);
+    const int blocks = primary && (ws.bin_entries || ws.pix_key) ? (ws.bins_expected ? 2048 : 16384) : walk_grid(groups);
     static const int steal = getenv("RTAMD_WALK_STEAL") ? atoi(getenv("RTAMD_WALK_STEAL")) : 1; // experiment hook
     if (steal && fc.t_eps >= 0.0f) { // (the shared nearest distance is ordered by its bits: distances must be positive)
         if (primary) {

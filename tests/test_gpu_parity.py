@@ -148,14 +148,37 @@ def test_screen_bins_and_tree_walk_agree_for_primary_rays(name, view):
             assert (ra["face_id"] >= 0).any()
 
 
-def test_automatic_choice_between_bins_and_tree():
-    """A dense mesh in a small image gives long lists per bin: the pass turns its bins down and walks the tree, and
-    the frames after it do not bin at all; the same mesh in a large image keeps its bins."""
-    small = R.Flyscene(model=scene_path("bunny"), output="").initialize(320, 240)
-    first, second = small.render()["stats"], small.render()["stats"]
-    assert first.primary_path == 0 and first.bin_entries > 38 * first.bins_nonempty > 0   # binned, then turned down
-    assert second.primary_path == 0 and second.bin_entries == 0                            # not binned any more
-    large = R.Flyscene(model=scene_path("bunny"), output="").initialize(1600, 1200)
+def test_automatic_choice_between_screen_space_and_tree():
+    """Primary rays are resolved face by face in screen space unless the faces are many against the pixels (a projection per
+    face then costs more than a tree walk per pixel) or too many faces reach round the eye for the per-pixel list; forced
+    screen bins keep their lists only while these stay short.  Whatever is chosen, the frame is the same."""
+    frames = {}
+    for size, path in (((96, 72), 0), ((320, 240), 1)):  # 10 faces per pixel, then 0.9
+        auto = R.Flyscene(model=scene_path("bunny"), output="").initialize(*size)
+        tree = R.Flyscene(model=scene_path("bunny"), output="", primary_rays=L.PRIMARY_RAYS_TREE).initialize(*size)
+        first, second = auto.render(), auto.render()
+        assert first["stats"].primary_path == path and second["stats"].primary_path == path
+        ref = tree.render()
+        assert ref["stats"].primary_path == 0
+        for r in (first, second):
+            assert np.array_equal(r["face_id"], ref["face_id"]) and np.array_equal(r["rgb"].view(np.uint32), ref["rgb"].view(np.uint32))
+        frames[size] = first
+    # the eye inside the mesh: hundreds of faces have a corner beside or behind the eye; the pass gives way to the tree walk,
+    # and the next frames of the view do not try again
+    inside = R.Flyscene(model=scene_path("toy"), output="").initialize(160, 120)
+    walk = R.Flyscene(model=scene_path("toy"), output="", primary_rays=L.PRIMARY_RAYS_TREE).initialize(160, 120)
+    for f in (inside, walk):
+        f.camera_translate(0.0, 0.0, 38.0)
+        f.camera_rotate(0.3, -0.7)
+    got = [inside.render() for _ in range(3)]
+    ref = walk.render()
+    for r in got:
+        assert np.array_equal(r["face_id"], ref["face_id"]) and np.array_equal(r["rgb"].view(np.uint32), ref["rgb"].view(np.uint32))
+    # forced bins: a dense mesh in a small image gives long lists, which AUTO-with-bins would turn down; forced, they are kept
+    small = R.Flyscene(model=scene_path("bunny"), output="", primary_rays=L.PRIMARY_RAYS_BINS).initialize(320, 240)
+    st = small.render()["stats"]
+    assert st.primary_path == 1 and st.bin_entries > 38 * st.bins_nonempty > 0
+    large = R.Flyscene(model=scene_path("bunny"), output="", primary_rays=L.PRIMARY_RAYS_BINS).initialize(1600, 1200)
     st = [large.render(face_ids=False)["stats"] for _ in range(2)][-1]
     assert st.primary_path == 1 and 0 < st.bin_entries <= 38 * st.bins_nonempty
 
