@@ -5,7 +5,7 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from raytracer_amd import tiles, workloads  # noqa: E402
 
 name = sys.argv[1]
