@@ -210,6 +210,7 @@ int ensure_workspace(rtamd_scene *s, FrameSlot &fs, size_t slots, size_t bins_ne
     const size_t total = layout_workspace(nullptr, slots, nshadow, bins, ntris, s->face_primary, sizes);
     HIP_TRY(hipMalloc(&fs.block, total));
     layout_workspace((char *)fs.block, slots, nshadow, bins, ntris, s->face_primary, fs.ws);
+    if (fs.ws.pix_key) HIP_TRY(hipMemset(fs.ws.pix_key, 0, (size_t)fs.ws.capacity * sizeof(unsigned long long)));
     fs.ws.bin_feedback = feedback;
     fs.ws.stage_feedback = stage_feedback;
     fs.bins = bins;
@@ -746,6 +747,13 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
             if (!(std::fabs(fc.cam_e[2] - 1.0f) > 1e-6f)) bins_ok = faces_ok = false;
         }
         fc.bins_x = bins_x, fc.bins_y = bins_y;
+        // four times the worst-case error of a projected on-screen corner (derivation: RT_BIN_MARGIN in kernels.hip), with the
+        // scale of the projection taken from this camera: pixels per unit of n = (H / 2) / tan(fovy / 2)
+        const double unit = 5.9604644775390625e-8; // 2^-24
+        const double px_per_n = std::max(0.5 * (double)p->height / std::max(1e-6, (double)std::fabs(fc.scale)),
+                                         0.5 * (double)p->width / std::max(1e-6, (double)std::fabs(fc.ax)));
+        const double bound = px_per_n * 26.0 * unit + 4.0 * unit * (double)p->width;
+        fc.raster_margin = std::max(raster_margin_floor(), (float)(4.0 * bound));
     }
     fs.ws.dir_y = fs.ws.dir_x + tiles_x * 8;
     Workspace ws_frame = fs.ws; // what the kernels of this frame see
@@ -801,7 +809,10 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
     // Every pass starts with prep_kernel: it fills the pass's screen-coordinate tables and zeroes the bin counters; the first
     // one also zeroes the stage and work counters of the frame, which lie right in front of them.
     const size_t bin_clear = bins_ok ? ((256 + sizeof(int32_t) * (size_t)ws_frame.num_bins + 15) & ~(size_t)15) : faces_ok ? 256 : 0;
-    const size_t key_clear = faces_ok ? pixels * sizeof(unsigned long long) : 0; // (the keys are indexed by local row and column)
+    // The per-pixel keys (indexed by local row and column) are zero between passes: the compaction kernel reads each once
+    // and puts the zero back, and a fresh workspace is cleared when it is allocated.  Only the array shared by all callers
+    // of the allocation-free entry point may hold anything.
+    const size_t key_clear = faces_ok && plain ? pixels * sizeof(unsigned long long) : 0;
     int stage = 0;
     for (int xs = 0; xs < S; ++xs)
         for (int ys = 0; ys < S; ++ys) {

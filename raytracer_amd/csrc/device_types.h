@@ -54,6 +54,7 @@ struct FrameConst {
     float lin_inv[9];
     float cam_e[3];
     int32_t bins_x, bins_y;
+    float raster_margin; // widening of projected boxes and triangles in pixels (error bound: RT_BIN_MARGIN in kernels.hip)
 };
 
 constexpr int kBinPixels = 4;   // screen bin edge; an 8x8 slot tile holds four bins

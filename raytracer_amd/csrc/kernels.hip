@@ -854,18 +854,34 @@ struct PixelBox {
     // (face_touches_bin) is left out.  Edge k runs from (ex[k], ey[k]) along (dx[k], dy[k]), oriented so that the
     // inside is on its left; coordinates are pixel indices (the sample offset of the pass is taken off).
     bool cull;
+    float margin;
     float ex[3], ey[3], dx[3], dy[3];
 };
 
-// Widening of the projected box and triangle, in pixels.  The projection rounds by about six float epsilons of the
-// pixel coordinate (1.5e-3 pixel at 8K), the exact test by less; a sixteenth of a pixel covers both forty times over.
-// It matters for faces smaller than a pixel (a distant mesh: hundreds per bin): their box holds a pixel centre with
-// probability (size + 2 margin)^2, and a quarter of a pixel made the longest lists 3-4 times longer than they had
-// to be (1.1 M-face field at 4K 5 % slower, one rank's share of eight 7 %).
+// Widening of the projected box and triangle, in pixels (FrameConst::raster_margin, set by the host to
+// max(kBinMarginFloor, four times the bound below)).
+//
+// Bound on the error of a projected corner, u = 2^-24 the unit roundoff.  project_point forms r = p - o, q = M r with M the
+// float rounding of the inverse camera matrix, s = q.z / (e.z - 1), n = q.xy / s - e.xy and the pixel from n:
+//   each component of q is off by at most 4 u R, R = |q.x| + |q.y| + |q.z| (three products, two sums, the rounding of M);
+//   s inherits that plus its own division: 4 u R + u s;
+//   n.x = q.x / s - e.x is then off by at most (8 R / s + 2) u (1 + |n.x|) / 2 <= (8 R / s + 2) u for a corner on the screen,
+//   where |n.x|, |n.y| <= 1 (tangent of half the field of view times the aspect) and so R <= 3 s;
+//   the pixel is n scaled by (W / 2) / (aspect tan(fovy / 2)) = (H / 2) / tan(fovy / 2) = 0.87 H at the reference's 60 degrees.
+// So a corner ON the screen lands within 0.87 H * 26 u + 4 u W of its true pixel position: 1.4e-6 H + 2.4e-7 W, i.e.
+// 0.0015 pixel at 1080p and 0.0077 pixel at 8K.  A corner far OFF the screen may be off by much more in the coordinate that
+// is on the screen (R / s is large), but only the box's extremes use it, and a wrong extreme at a corner changes which
+// pixels are tested only next to that corner, which is off the screen.  Corners with s <= 1e-6 R count as unprojectable
+// and send the face to the per-pixel list; the edge functions are only used with every corner within 16384 pixels
+// (R / s <= 20 at 1080p: 0.009 pixel).  The exact test's own rounding moves a face's boundary by a few u of the face's
+// size in pixels (0.001 pixel for a face 10^4 pixels wide).  The floor of a sixteenth of a pixel is eight times the 8K bound;
+// beyond that the host scales the margin with the image.
+// It matters that the margin is not larger than needed for faces smaller than a pixel (a distant mesh): their box holds a
+// pixel centre with probability (size + 2 margin)^2, and a quarter of a pixel made the work 3-4 times what it had to be.
 #ifndef RT_BIN_MARGIN
 #define RT_BIN_MARGIN 0.0625f
 #endif
-constexpr float kBinMargin = RT_BIN_MARGIN;
+constexpr float kBinMarginFloor = RT_BIN_MARGIN;
 
 // pixel position of a world point: inverse of camera_direction.  false: the point is not in front of the eye.
 // `behind`: the point lies behind the eye plane by far more than any rounding here or in the exact test.
@@ -915,7 +931,7 @@ __device__ __forceinline__ ProjectedFace project_face(const DeviceScene &sc, con
     if (ok0 && ok1 && ok2) {
         // pixel (x, y) samples at (x + sub_x, y + sub_y): shift the box instead of the samples; the margin covers
         // the rounding of the projection (about 1e-3 pixel at 8K) and of the exact test many times over
-        const float margin = kBinMargin;
+        const float margin = fc.raster_margin;
         xlo = fminf(fminf(f.x0, f.x1), f.x2) - margin - fc.sub_x, xhi = fmaxf(fmaxf(f.x0, f.x1), f.x2) + margin - fc.sub_x;
         ylo = fminf(fminf(f.y0, f.y1), f.y2) - margin - fc.sub_y, yhi = fmaxf(fmaxf(f.y0, f.y1), f.y2) + margin - fc.sub_y;
     } else {
@@ -935,6 +951,7 @@ __device__ __forceinline__ ProjectedFace project_face(const DeviceScene &sc, con
 __device__ __forceinline__ PixelBox face_bins(const DeviceScene &sc, const FrameConst &fc, int tri) {
     PixelBox b;
     b.empty = false, b.big = false, b.cull = false;
+    b.margin = fc.raster_margin;
     const ProjectedFace pf = project_face(sc, fc, tri);
     if (pf.empty) {
         b.empty = true;
@@ -971,7 +988,7 @@ __device__ __forceinline__ PixelBox face_bins(const DeviceScene &sc, const Frame
     return b;
 }
 
-// Can a pixel of bin (x, y) lie inside the projected triangle widened by kBinMargin?  E(r) = dx (r.y - ey) - dy (r.x - ex)
+// Can a pixel of bin (x, y) lie inside the projected triangle widened by the margin?  E(r) = dx (r.y - ey) - dy (r.x - ex)
 // is >= 0 left of an edge; moving r by up to the margin in x and y changes E by at most margin (|dx| + |dy|), so a bin
 // whose most favourable corner stays below minus that lies outside for good.
 __device__ __forceinline__ bool face_touches_bin(const PixelBox &b, int x, int y) {
@@ -983,7 +1000,7 @@ __device__ __forceinline__ bool face_touches_bin(const PixelBox &b, int x, int y
         const float cy = b.dx[k] >= 0.0f ? ry1 : ry0; // E grows with r.y when dx > 0 ...
         const float cx = b.dy[k] >= 0.0f ? rx0 : rx1; // ... and falls with r.x when dy > 0
         const float e = b.dx[k] * (cy - b.ey[k]) - b.dy[k] * (cx - b.ex[k]);
-        if (e < -kBinMargin * (fabsf(b.dx[k]) + fabsf(b.dy[k]))) return false;
+        if (e < -b.margin * (fabsf(b.dx[k]) + fabsf(b.dy[k]))) return false;
     }
     return true;
 }
@@ -1746,8 +1763,10 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
             if (valid) {
                 float tbest = FLT_MAX;
                 int best_rank = -1;
-                const unsigned long long held = ws.pix_key[(size_t)row * (size_t)fc.width + (size_t)x];
+                unsigned long long *const cell = ws.pix_key + ((size_t)row * (size_t)fc.width + (size_t)x);
+                const unsigned long long held = *cell;
                 if (held != 0ull) {
+                    *cell = 0ull; // every pixel's key is read exactly once per pass: left clean for the next one
                     tbest = __int_as_float((int)(unsigned)(~held >> 32));
                     best_rank = 0x7fffffff - (int)(unsigned)(~held & 0xffffffffull);
                     tri = sc.tri_of_rank[best_rank];
@@ -1783,6 +1802,8 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
         } else {
             tri = valid ? ws.slot_tri[slot] : -2;
             t_found = valid && tri != -2 ? ws.slot_t[slot] : 0.0f;
+            // the face raster ran but gave way to the tree walk: its keys are dropped here
+            if (PRIMARY && ws.pix_key != nullptr && valid) ws.pix_key[(size_t)row * (size_t)fc.width + (size_t)x] = 0ull;
         }
         t_of[j] = t_found;
         const bool hit = tri != -2;
@@ -2133,6 +2154,8 @@ int walk_grid(long long groups) {
     return (int)(b < 8 ? 8 : b);
 }
 } // namespace
+
+float raster_margin_floor() { return kBinMarginFloor; }
 
 void launch_prep(const FrameConst &fc, const Workspace &ws, void *zero, size_t zero_bytes, void *zero_b, size_t zero_b_bytes, hipStream_t stream) {
     const int zero16 = (int)((zero_bytes + 15) / 16), zero_b16 = (int)((zero_b_bytes + 15) / 16);

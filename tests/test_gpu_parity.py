@@ -148,6 +148,69 @@ def test_screen_bins_and_tree_walk_agree_for_primary_rays(name, view):
             assert (ra["face_id"] >= 0).any()
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_projection_margins_under_attack(seed):
+    """Faces chosen to strain the screen-space candidate structures, whose boxes are widened by a sixteenth of a pixel only
+    (the bound on a projected corner's error is 0.008 pixel at 8K): corners almost in the eye plane (depth 1e-6 .. 1e-3 of
+    their distance from the eye), corners that project near the 16384-pixel limit of the edge functions, faces seen
+    edge-on, in an image 7680 pixels wide and from an eye close to the geometry.  Face raster and screen bins against the
+    tree walk, bit for bit."""
+    rng = np.random.default_rng(500 + seed)
+    W, H = 7680, 240
+    aspect, tan_half = W / H, np.tan(np.radians(30.0))
+    eye = np.array([0.0, 0.0, 2.0])
+
+    def on_screen(n, depth_lo=0.5, depth_hi=3.0):
+        depth = rng.uniform(depth_lo, depth_hi, n)
+        nx, ny = rng.uniform(-1.0, 1.0, n) * aspect * tan_half, rng.uniform(-1.0, 1.0, n) * tan_half
+        return np.stack([nx * depth, ny * depth, 2.0 - depth], 1)
+
+    tris = []
+    n = 1500
+    # (a) one corner almost in the eye plane, far to the side; the other two ordinary
+    a0 = on_screen(n)
+    a1 = a0 + rng.uniform(-0.3, 0.3, (n, 3))
+    reach = rng.uniform(0.2, 3.0, n)
+    delta = 10.0 ** rng.uniform(-6.5, -3.0, n)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    a2 = np.stack([reach * np.cos(ang), reach * np.sin(ang), 2.0 - delta * reach], 1)
+    tris.append(np.stack([a0, a1, a2], 1))
+    # (b) one corner projecting near +-16384 pixels (the limit up to which the projected edges are used)
+    b0, b1 = on_screen(n), on_screen(n)
+    depth = rng.uniform(0.5, 2.0, n)
+    px = rng.choice([-1.0, 1.0], n) * (16384.0 + rng.uniform(-40.0, 40.0, n))
+    nxb = (2.0 * px / W - 1.0) * aspect * tan_half
+    b2 = np.stack([nxb * depth, rng.uniform(-0.3, 0.3, n) * depth, 2.0 - depth], 1)
+    tris.append(np.stack([b0, b1, b2], 1))
+    # (c) edge-on: two corners on (almost) one line of sight
+    c0 = on_screen(n)
+    c1 = eye + (c0 - eye) * rng.uniform(1.2, 2.5, (n, 1)) + rng.normal(0, 1e-5, (n, 3))
+    c2 = c0 + rng.uniform(-0.2, 0.2, (n, 3))
+    tris.append(np.stack([c0, c1, c2], 1))
+    # (d) filler: faces of a pixel or so, several per pixel column
+    d0 = on_screen(6 * n, 1.0, 3.0)
+    tris.append(np.stack([d0, d0 + rng.normal(0, 0.002, (6 * n, 3)), d0 + rng.normal(0, 0.002, (6 * n, 3))], 1))
+    tri = np.concatenate(tris).astype(np.float32)
+    verts = tri.reshape(-1, 3)
+    faces = np.arange(len(verts), dtype=np.int32).reshape(-1, 3)
+    mats = [dict(ka=[0.1] * 3, kd=[0.3 + 0.2 * m, 0.8 - 0.2 * m, 0.4], ks=[0.0] * 3, shininess=8.0) for m in range(3)]
+    arrays = (verts, None, faces, rng.integers(0, 3, len(faces)).astype(np.int32), mats)
+    kw = dict(arrays=arrays, lights=[(-1.0, 1.0, 1.0)], soft_points=0, normalize_model=False, output="")
+    auto = R.Flyscene(**kw).initialize(W, H)
+    bins = R.Flyscene(primary_rays=L.PRIMARY_RAYS_BINS, **kw).initialize(W, H)
+    tree = R.Flyscene(primary_rays=L.PRIMARY_RAYS_TREE, shadow_rays=L.SHADOW_RAYS_TREE, **kw).initialize(W, H)
+    for params in (dict(), dict(row_tile=16, num_parts=8, part=5)):
+        for f in (auto, bins, tree):
+            f.set_params(max_reflections=0, **params)
+        ra, rb, rt = auto.render(), bins.render(), tree.render()
+        assert rt["stats"].primary_path == 0 and rb["stats"].primary_path == 1
+        assert (rt["face_id"] >= 0).sum() > 2000
+        for r in (ra, rb):
+            assert np.array_equal(r["face_id"], rt["face_id"]), params
+            assert np.array_equal(r["rgb"].view(np.uint32), rt["rgb"].view(np.uint32)), params
+            assert (r["stats"].rays_shadow, r["stats"].hits) == (rt["stats"].rays_shadow, rt["stats"].hits)
+
+
 def test_automatic_choice_between_screen_space_and_tree():
     """Primary rays are resolved face by face in screen space unless the faces are many against the pixels (a projection per
     face then costs more than a tree walk per pixel) or too many faces reach round the eye for the per-pixel list; forced
@@ -711,16 +774,17 @@ def test_faces_smaller_than_a_pixel_bins_and_grids_against_the_tree(seed, size):
     a = R.Flyscene(primary_rays=L.PRIMARY_RAYS_BINS, **kw).initialize(W, H)
     b = R.Flyscene(primary_rays=L.PRIMARY_RAYS_TREE, shadow_rays=L.SHADOW_RAYS_TREE, **kw).initialize(W, H)
     d = R.Flyscene(primary_rays=L.PRIMARY_RAYS_BINS, builder=L.BUILDER_DEVICE_LBVH, **kw).initialize(W, H)
+    c = R.Flyscene(**kw).initialize(W, H)  # the automatic choice: every face against the pixels of its own box
     assert a.info().shadow_grid_entries > 0 and d.info().shadow_grid_entries == a.info().shadow_grid_entries
-    for params in (dict(), dict(ssaa_level=2), dict(row_tile=16, num_parts=4, part=3)):
+    for params in (dict(), dict(ssaa_level=2), dict(row_tile=16, num_parts=4, part=3), dict(row_tile=5, num_parts=3, part=1)):
         if W * H > 10**6 and "ssaa_level" in params:
             continue
-        for f in (a, b, d):
+        for f in (a, b, c, d):
             f.set_params(max_reflections=0, **params)
-        ra, rb, rd = a.render(), b.render(), d.render()
-        assert ra["stats"].primary_path == 1 and rb["stats"].primary_path == 0
+        ra, rb, rc, rd = a.render(), b.render(), c.render(), d.render()
+        assert ra["stats"].primary_path == 1 and rb["stats"].primary_path == 0 and rc["stats"].primary_path == 1
         assert (ra["face_id"] >= 0).sum() > 200
-        for r in (ra, rd):
+        for r in (ra, rc, rd):
             assert np.array_equal(r["face_id"], rb["face_id"]), (size, params)
             assert np.array_equal(r["rgb"].view(np.uint32), rb["rgb"].view(np.uint32)), (size, params)
             assert (r["stats"].rays_shadow, r["stats"].hits) == (rb["stats"].rays_shadow, rb["stats"].hits)
