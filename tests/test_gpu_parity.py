@@ -788,3 +788,33 @@ def test_faces_smaller_than_a_pixel_bins_and_grids_against_the_tree(seed, size):
             assert np.array_equal(r["face_id"], rb["face_id"]), (size, params)
             assert np.array_equal(r["rgb"].view(np.uint32), rb["rgb"].view(np.uint32)), (size, params)
             assert (r["stats"].rays_shadow, r["stats"].hits) == (rb["stats"].rays_shadow, rb["stats"].hits)
+
+
+def test_ply_scene_renders_like_its_obj_and_p6_output_matches_the_device_bytes(tmp_path):
+    """Formats either side of the path, on the GPU: a binary PLY holding toy.obj's vertices, normals and faces (with toy.mtl
+    beside it) must render the frame of the OBJ -- checked against the oracle's frame of the OBJ -- and the binary PPM
+    written from that frame must hold the bytes rtamd_quantize_ppm produces on the device (utils/ppmIO.hpp:188-209)."""
+    import shutil
+    import torch
+
+    from test_formats import write_ply
+
+    obj = R.Flyscene(model=scene_path("toy"), output="").initialize(16, 16, upload=False).arrays()
+    v, n, f = obj["raw_vertices"].reshape(-1, 3), obj["raw_normals"].reshape(-1, 3), obj["face_vertex_ids"].reshape(-1, 3)
+    write_ply(str(tmp_path / "toy.ply"), v, n, f, binary=True, colors=True)
+    shutil.copy(scene_path("toy")[:-4] + ".mtl", tmp_path / "toy.mtl")
+    W, H = 128, 96
+    out = tmp_path / "frame.p6.ppm"
+    fly = R.Flyscene(model=str(tmp_path / "toy.ply"), output=str(out)).initialize(W, H)
+    _, orc = make_pair("toy", width=W, height=H)  # the oracle reads the OBJ
+    r = compare(fly, orc, W, H)
+    assert_parity(r)
+    assert r["got"]["stats"].rays_bounce > 0  # toy's Ks 0.485 reflects: every kernel of the frame took part
+    # the file Flyscene::raytraceScene writes (binary form by the file name) against the device's quantisation of the frame
+    fly.raytraceScene()
+    raw = out.read_bytes()
+    head = ("P6\n%d %d\n255\n" % (W, H)).encode()
+    assert raw.startswith(head) and len(raw) == len(head) + W * H * 3
+    dev = torch.zeros(W * H * 3, dtype=torch.uint8, device="cuda")
+    tiles.quantize_ppm(torch.from_numpy(r["got"]["rgb"]).cuda(), dev)
+    assert np.array_equal(np.frombuffer(raw[len(head):], np.uint8), dev.cpu().numpy())
