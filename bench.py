@@ -271,8 +271,11 @@ def main():
     # below the number of hardware queues, or the waits stall for good.
     queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
     piped = world > 1 or a.force_pipeline
-    # a frame's workspace: 44 four-byte planes per ray slot and two bytes per shadow ray of a slot
-    slot_bytes = (W * ((H + world - 1) // world)) * (176 + 2 * len(w["lights"]) * (1 + w["soft_points"]))
+    # a frame's workspace per ray slot (rtamd_scene_workspace_bytes): 48 bytes + one per shadow ray without reflections, 130 with
+    # one bounce, 210 with more
+    ns = len(w["lights"]) * (1 + w["soft_points"])
+    per_slot = 48 + ns if w["max_reflections"] == 0 else (112 if w["max_reflections"] == 1 else 192) + 2 * ns
+    slot_bytes = (W * ((H + world - 1) // world)) * per_slot
     in_flight = max(1, min(a.in_flight or (8 if piped else 16), 16, max(1, queues - 2) if piped else max(4, queues),
                            max(2, int(64e9 // max(slot_bytes, 1)))))
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(in_flight - 1)]
@@ -461,6 +464,7 @@ def main():
                 "bvh": {"nodes": int(info.num_nodes), "leaves": int(info.num_leaves), "depth": int(info.depth),
                         "build_ms": round(float(info.build_ms), 1),
                         "builder": ("host SAH", "device LBVH")[int(info.builder)], "hierarchy_ms": round(float(info.hierarchy_ms), 1), "device_MB": round(info.device_bytes / 1e6, 2)},
+                "workspace_MB": round(fly.workspace_bytes() / 1e6, 1),
                 "scene_init_s": round(init_s, 2),
             },
         }

@@ -204,6 +204,11 @@ void rtamd_render_params_default(rtamd_render_params *p, int32_t width, int32_t 
 int rtamd_scene_create(const rtamd_scene_desc *desc, const rtamd_build_params *build, rtamd_scene **out);
 int rtamd_scene_destroy(rtamd_scene *scene);
 int rtamd_scene_get_info(const rtamd_scene *scene, rtamd_scene_info *info);
+/* Device memory the scene holds beside its own data (rtamd_scene_info::device_bytes): the work buffers of the frames in
+ * flight, one set per stream it has been rendered on (hit lists, ray queues, shadow results, per-pixel keys), sized for the
+ * largest image and deepest recursion seen so far, plus the staging of rtamd_render.  A frame without reflections takes
+ * about 40 + lights * samples_per_light bytes per pixel, one bounce about 130, deeper recursion about 210. */
+int rtamd_scene_workspace_bytes(const rtamd_scene *scene, uint64_t *bytes);
 
 /* Host only (no device needed): rank[f] = position of face f in the order in which the reference's
  * triangleIntersection meets the faces (leaves of boundingBox::splitBox in lower/upper preorder,

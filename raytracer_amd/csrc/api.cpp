@@ -73,6 +73,8 @@ struct FrameSlot {
     Workspace ws{};
     void *block = nullptr;
     size_t bins = 0;              // screen bins the workspace holds
+    int depths = 0;               // recursion levels it was laid out for (1, 2, or 3 = any)
+    size_t bytes = 0;             // size of `block`
     hipStream_t stream = nullptr; // the caller's stream the slot serves
     hipEvent_t done = nullptr;    // recorded behind the slot's most recent frame
     bool used = false;            // `done` has been recorded at least once
@@ -142,7 +144,9 @@ int upload(void **dst, const std::vector<T> &src, uint64_t *bytes) {
 // Lays the work buffers of one frame in flight out behind `base` and returns the bytes they take; with base == nullptr
 // nothing is written through `ws` but sizes, so the same code answers "how much" and "where".
 // `slots` = ray slots of the local image = whole 8x8 tiles (a multiple of 64); bins == 0: no screen bins.
-size_t layout_workspace(char *base, size_t slots, size_t nshadow, size_t bins, size_t ntris, bool keys, Workspace &ws) {
+// `depths` = recursion levels the frames will have (1: no reflections): a frame without reflections needs no ray queues and
+// one hit list, one with a single bounce one queue; three queues and both lists rotate from two bounces on.
+size_t layout_workspace(char *base, size_t slots, size_t nshadow, size_t bins, size_t ntris, bool keys, int depths, Workspace &ws) {
     const size_t cap = (slots + 255) & ~(size_t)255; // every plane starts 1 KiB aligned
     const size_t head = 4096;                        // stage counters + work counters
     static_assert(sizeof(StageCounters) * kMaxStages <= 2048, "counter block too small");
@@ -170,14 +174,27 @@ size_t layout_workspace(char *base, size_t slots, size_t nshadow, size_t bins, s
     align(1024);
     ws.slot_tri = (int32_t *)take(cap * 4);
     ws.slot_t = (float *)take(cap * 4);
-    for (HitList &h : ws.hits) {
-        h.slot = (int32_t *)take(cap * 4);
-        h.tri = (int32_t *)take(cap * 4);
-        h.child = (int32_t *)take(cap * 4);
-        h.p = (float *)take(3 * cap * 4);
+    for (int k = 0; k < 2; ++k) { // by depth & 1
+        HitList &h = ws.hits[k];
+        if (k < depths) {
+            h.slot = (int32_t *)take(cap * 4);
+            h.tri = (int32_t *)take(cap * 4);
+            h.child = (int32_t *)take(cap * 4);
+            h.p = (float *)take(3 * cap * 4);
+            ws.clear[k] = (uint8_t *)take(nshadow * cap);
+            align(256);
+        } else {
+            h = ws.hits[0];
+            ws.clear[k] = ws.clear[0];
+        }
     }
-    for (float *&q : ws.queue) q = (float *)take(10 * cap * 4);
-    for (uint8_t *&c : ws.clear) c = (uint8_t *)take(nshadow * cap);
+    // queue[(d + 1) % 3] holds the rays spawned at depth d: one bounce only ever touches queue[1]
+    for (int k = 0; k < 3; ++k) ws.queue[k] = nullptr;
+    if (depths == 2) {
+        ws.queue[1] = (float *)take(10 * cap * 4);
+    } else if (depths > 2) {
+        for (float *&q : ws.queue) q = (float *)take(10 * cap * 4);
+    }
     if (keys) {
         align(256);
         ws.pix_key = (unsigned long long *)take(cap * 8);
@@ -195,8 +212,9 @@ size_t layout_workspace(char *base, size_t slots, size_t nshadow, size_t bins, s
     return (size_t)(p - (uintptr_t)base) + 1024;
 }
 
-int ensure_workspace(rtamd_scene *s, FrameSlot &fs, size_t slots, size_t bins_needed) {
-    if (fs.block && (size_t)fs.ws.capacity >= slots && fs.bins >= (s->bin_primary ? bins_needed : 0) && (fs.ws.pix_key != nullptr) == s->face_primary)
+int ensure_workspace(rtamd_scene *s, FrameSlot &fs, size_t slots, size_t bins_needed, int depths) {
+    if (fs.block && (size_t)fs.ws.capacity >= slots && fs.bins >= (s->bin_primary ? bins_needed : 0) && (fs.ws.pix_key != nullptr) == s->face_primary &&
+        fs.depths >= std::min(depths, 3))
         return RTAMD_OK;
     if (fs.block) {
         HIP_TRY(hipFree(fs.block)); // waits for the device: no frame still reads the old block
@@ -207,13 +225,15 @@ int ensure_workspace(rtamd_scene *s, FrameSlot &fs, size_t slots, size_t bins_ne
     const size_t bins = s->bin_primary ? bins_needed : 0; // sized for the whole image this workspace may see
     int32_t *const feedback = fs.ws.bin_feedback, *const stage_feedback = fs.ws.stage_feedback;
     Workspace sizes{};
-    const size_t total = layout_workspace(nullptr, slots, nshadow, bins, ntris, s->face_primary, sizes);
+    const size_t total = layout_workspace(nullptr, slots, nshadow, bins, ntris, s->face_primary, depths, sizes);
     HIP_TRY(hipMalloc(&fs.block, total));
-    layout_workspace((char *)fs.block, slots, nshadow, bins, ntris, s->face_primary, fs.ws);
+    layout_workspace((char *)fs.block, slots, nshadow, bins, ntris, s->face_primary, depths, fs.ws);
     if (fs.ws.pix_key) HIP_TRY(hipMemset(fs.ws.pix_key, 0, (size_t)fs.ws.capacity * sizeof(unsigned long long)));
     fs.ws.bin_feedback = feedback;
     fs.ws.stage_feedback = stage_feedback;
     fs.bins = bins;
+    fs.depths = std::min(depths, 3);
+    fs.bytes = total;
     return RTAMD_OK;
 }
 
@@ -916,7 +936,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     if (shape.pixels == 0) return RTAMD_OK;
     FrameSlot *slot = nullptr;
     if ((rc = acquire_slot(s, stream, &slot)) != RTAMD_OK) return rc;
-    rc = ensure_workspace(s, *slot, shape.slots, (size_t)shape.bins_x * (size_t)shape.bins_y);
+    rc = ensure_workspace(s, *slot, shape.slots, (size_t)shape.bins_x * (size_t)shape.bins_y, shape.depths);
     if (rc != RTAMD_OK) return rc;
     return enqueue_frame(s, *slot, shape, cam, p, rgb, face_id, t_hit, stream, /*plain=*/false);
 }
@@ -938,23 +958,31 @@ int rtamd_render_device_noalloc(rtamd_scene *s, const rtamd_camera *cam, const r
     const size_t ntris = (size_t)s->info.num_device_faces;
     const size_t bins = s->bin_primary ? (size_t)shape.bins_x * (size_t)shape.bins_y : 0;
     Workspace sizes{};
-    const size_t need_plain = layout_workspace(nullptr, shape.slots, shape.nshadow, 0, ntris, false, sizes);
+    const size_t need_plain = layout_workspace(nullptr, shape.slots, shape.nshadow, 0, ntris, false, shape.depths, sizes);
     if (need_plain > kScratchBytes)
         return fail(RTAMD_ERR_LIMIT, "a frame of %d x %d pixels with %zu shadow rays per hit needs %zu bytes of work buffers; "
                     "rtamd_render_device_noalloc holds %zu (use rtamd_render_device)", p->width, shape.local_rows, shape.nshadow, need_plain, kScratchBytes);
     // the buffers of the screen-space pass for the primary rays (per-pixel keys, or bins) only when they fit as well
-    const bool with_keys = s->face_primary && layout_workspace(nullptr, shape.slots, shape.nshadow, 0, ntris, true, sizes) <= kScratchBytes;
-    const bool with_bins = bins > 0 && layout_workspace(nullptr, shape.slots, shape.nshadow, bins, ntris, false, sizes) <= kScratchBytes;
+    const bool with_keys = s->face_primary && layout_workspace(nullptr, shape.slots, shape.nshadow, 0, ntris, true, shape.depths, sizes) <= kScratchBytes;
+    const bool with_bins = bins > 0 && layout_workspace(nullptr, shape.slots, shape.nshadow, bins, ntris, false, shape.depths, sizes) <= kScratchBytes;
     char *base = s->scratch; // looked up when the scene was created
     if (!base && (rc = scratch_pointer(dev, &base)) != RTAMD_OK) return rc;
     FrameSlot &fs = s->static_slot;
-    layout_workspace(base, shape.slots, shape.nshadow, with_bins ? bins : 0, ntris, with_keys, fs.ws);
+    layout_workspace(base, shape.slots, shape.nshadow, with_bins ? bins : 0, ntris, with_keys, shape.depths, fs.ws);
     fs.block = base;
     fs.bins = with_bins ? bins : 0;
     fs.stream = (hipStream_t)hip_stream;
     return enqueue_frame(s, fs, shape, cam, p, rgb, face_id, t_hit, (hipStream_t)hip_stream, /*plain=*/true);
 }
 
+
+int rtamd_scene_workspace_bytes(const rtamd_scene *s, uint64_t *bytes) {
+    if (!s || !bytes) return fail(RTAMD_ERR_INVALID, "null scene or output");
+    uint64_t total = 0;
+    for (int i = 0; i < s->num_slots; ++i) total += s->slots[i].bytes;
+    *bytes = total + (uint64_t)s->staging_pixels * 16;
+    return RTAMD_OK;
+}
 
 int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
     if (!s || !st) return fail(RTAMD_ERR_INVALID, "null scene or stats");
@@ -988,11 +1016,11 @@ int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
     if (s->last_frame_slot->binned) {
         BinState bs;
         HIP_TRY(hipMemcpy(&bs, ws_last.bin_state, sizeof bs, hipMemcpyDeviceToHost));
-        st->bin_entries = (uint32_t)bs.total;
+        st->bin_entries = (uint32_t)std::min<unsigned long long>(bs.total, 0xffffffffull);
         st->bins_nonempty = (uint32_t)bs.nonempty;
         st->bin_overflow = bs.fallback;
         const long long limit = s->bin_always ? 0x7fffffffll : (long long)kMaxAverageBinList;
-        st->primary_path = !bs.fallback && (long long)bs.num_big <= 4 * limit && (long long)bs.total <= limit * (long long)std::max(bs.nonempty, 1) ? 1 : 0;
+        st->primary_path = !bs.fallback && (long long)bs.num_big <= 4 * limit && bs.total <= (unsigned long long)(limit * (long long)std::max(bs.nonempty, 1)) ? 1 : 0;
     }
     for (size_t i = 0; i < s->events_used; ++i) {
         float ms = 0.0f;

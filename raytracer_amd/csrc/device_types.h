@@ -62,10 +62,11 @@ constexpr int kBigBins = 256;   // a face covering more bins goes to the list ev
 
 // State of the per-pass screen binning, zeroed with the stage counters.
 struct BinState {
-    int32_t total;    // entries handed out so far (bin ranges are claimed block by block)
+    unsigned long long total; // entries asked for so far (bin ranges are claimed block by block); 64 bits: a face may enter 256 bins
     int32_t num_big;  // faces in the big list
     int32_t fallback; // 1: the entry buffer is too small for this view -> the primary rays walk the tree
     int32_t nonempty; // bins that hold at least one face
+    int32_t pad;
 };
 
 // Longest average list (entries per non-empty bin) for which the bins beat the tree: every pixel of a bin

@@ -245,6 +245,14 @@ constexpr int kMinGroupShift = RT_MIN_GROUP_SHIFT; // narrowest group: 16 rays
 constexpr int kSplitRaysBelow = RT_SPLIT_RAYS_BELOW;           // bounce launches below this many rays put several lanes on a ray
 constexpr int kFullChipWaves = 8192;               // a launch with fewer groups leaves SIMDs of the 256 CUs idle
 
+// Orders this wave's LDS traffic against its own later LDS traffic (the hardware keeps a wave's LDS operations in
+// order; this keeps the compiler from moving them).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Entry `sp` of the traversal stack.  The empty asm keeps the two loads in separate blocks: merged into one
 // load through a selected generic pointer they would become flat accesses.
 __device__ __forceinline__ int stack_read(const int *stack, const int *deep, int sp) {
@@ -391,6 +399,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
                 }
             }
             if (sub == 0) *cut_bits = __float_as_int(tbest);
+            wave_sync(); // the other lanes of the ray read it next
         }
 
         for (;;) {
@@ -594,13 +603,6 @@ __device__ __forceinline__ RaySetup setup_ray(V3 o, V3 d) {
 // positive, so their bit patterns order like unsigned integers.
 __device__ __forceinline__ unsigned long long hit_key(float t, int rank) {
     return ((unsigned long long)(unsigned)__float_as_int(t) << 32) | (unsigned long long)(unsigned)(0x7fffffff - rank);
-}
-// Orders this wave's LDS traffic against its own later LDS traffic (the hardware keeps a wave's LDS operations in
-// order; this keeps the compiler from moving them).
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // (`block` of `nblocks`: the launch's block index and grid, or this kernel's share of a launch it shares with another)
@@ -1105,14 +1107,14 @@ __global__ __launch_bounds__(256) void bin_offsets_kernel(Workspace ws) {
     if (lane == 0) s_full[wave] = full;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int n = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        int base = n ? atomicAdd(&ws.bin_state->total, n) : 0;
+        const long long n = (long long)s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        unsigned long long base = n ? atomicAdd(&ws.bin_state->total, (unsigned long long)n) : 0ull;
         if (s_full[0] + s_full[1] + s_full[2] + s_full[3]) atomicAdd(&ws.bin_state->nonempty, s_full[0] + s_full[1] + s_full[2] + s_full[3]);
-        if (base + n > ws.bin_capacity) {
+        if (base + (unsigned long long)n > (unsigned long long)ws.bin_capacity) { // (the fill pass then leaves the bins alone)
             ws.bin_state->fallback = 1;
             base = 0;
         }
-        s_base = base;
+        s_base = (int)base;
     }
     __syncthreads();
     int start = s_base + incl - mine;
@@ -1131,7 +1133,7 @@ template <bool AGG>
 __global__ __launch_bounds__(256) void bin_fill_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int num_tris) {
     const int tri = (int)(blockIdx.x * 256 + threadIdx.x);
     if (tri == 0 && ws.bin_feedback) {
-        ws.bin_feedback[0] = ws.bin_state->total, ws.bin_feedback[1] = ws.bin_state->nonempty;
+        ws.bin_feedback[0] = (int)min(ws.bin_state->total, 0x7fffffffull), ws.bin_feedback[1] = ws.bin_state->nonempty;
         ws.bin_feedback[2] = bins_accepted(ws) ? 0 : 1, ws.bin_feedback[3] = 1;
     }
     if (!bins_accepted(ws)) return;

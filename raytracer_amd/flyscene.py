@@ -207,6 +207,11 @@ class Flyscene:
         L.check(self.lib.rtamd_render_stats(self.scene, C.byref(st)), "rtamd_render_stats")
         return st
 
+    def workspace_bytes(self):
+        n = C.c_uint64()
+        L.check(self.lib.rtamd_scene_workspace_bytes(self.scene, C.byref(n)), "rtamd_scene_workspace_bytes")
+        return n.value
+
     def info(self):
         i = L.SceneInfo()
         L.check(self.lib.rtamd_scene_get_info(self.scene, C.byref(i)), "rtamd_scene_get_info")
