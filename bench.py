@@ -208,7 +208,7 @@ def profile_table(workload):
                 avg_us[m.group(1)] = float(row["AverageNs"]) / 1e3
     table = {}
     for kern, c in sorted(counters.items()):
-        if "true>" in kern.replace(" ", "") and kern.startswith(("walk", "shadow", "raster")):
+        if kern.replace(" ", "").endswith("true>") and not kern.startswith(("compact", "shade")):
             continue  # the instrumented (work-counting) variants are not part of a timed frame
         if "SQ_INSTS_VALU" not in c:
             continue
@@ -469,8 +469,8 @@ def main():
             },
         }
         # ---- roofline of the dominant kernel (slowest rank's event times; work summed over ranks / ranks).
-        # Three groups are timed: the BVH walk for closest hits, the shadow-ray kernel, and the screen-bin pass of
-        # the primary rays (three small binning kernels + raster_kernel, timed as one).
+        # Three groups are timed: the BVH walk for closest hits, the shadow-ray kernel, and the screen-space pass of the
+        # primary rays (face_raster_kernel; with forced bins the three binning kernels + raster_kernel, timed as one).
         if not a.no_kernel_events and kmax[3].item() > 0:
             group_ms = [kmax[0].item(), kmax[1].item(), kmax[7].item()]
             group_launches = [kmax[2].item(), kmax[3].item(), kmax[8].item()]
@@ -478,10 +478,13 @@ def main():
             flops = [wl[3 * g] * FLOPS_BOX + wl[3 * g + 1] * FLOPS_PLANE + wl[3 * g + 2] * FLOPS_EDGE for g in range(3)]
             byts = [wl[3 * g] * BYTES_BOX + wl[3 * g + 1] * BYTES_PLANE + wl[3 * g + 2] * BYTES_EDGE for g in range(3)]
             k = max(range(3), key=lambda g: group_ms[g])
-            closest_key = "walk_kernel<1, false>" if group_launches[2] > 0 or w["max_reflections"] > 0 else "walk_kernel<0, false>"
+            bounce = w["max_reflections"] > 0 and rays[2].item() > 0
+            closest_key = "walk_steal_kernel<1, false>" if bounce else "walk_steal_kernel<0, false>"
             shadow_key = "shadow_grid_kernel<false>" if info.shadow_grid_entries else "walk_kernel<2, false>"
-            kname = ("walk_kernel<closest hit>", "shadow_grid_kernel" if info.shadow_grid_entries else "walk_kernel<shadow>",
-                     "raster_kernel (+ bin_count, bin_offsets, bin_fill)")[k]
+            raster_key = "raster_kernel<false>" if a.primary_rays == 2 else "face_raster_kernel<false>"
+            kname = ("walk_steal_kernel (closest hits of the reflection rays)" if bounce else "walk_steal_kernel (closest hits, primary rays)",
+                     "shadow_grid_kernel" if info.shadow_grid_entries else "walk_kernel<shadow>",
+                     "raster_kernel (+ bin_count, bin_offsets, bin_fill)" if a.primary_rays == 2 else "face_raster_kernel")[k]
             launches_per_frame = group_launches[k] / a.steps
             per_launch_ms = group_ms[k] / group_launches[k]
             flops_launch = flops[k] / launches_per_frame
@@ -492,7 +495,7 @@ def main():
             # fractions are far from 1 and why `traffic`, the bytes that really reached HBM, is below the algorithmic
             # bytes: the caches serve the re-reads.
             ach_b = bytes_launch / (per_launch_ms * 1e-3) / 1e9
-            traffic, traffic_src = pmc_traffic(name, (closest_key, shadow_key, "raster_kernel<false>")[k])
+            traffic, traffic_src = pmc_traffic(name, (closest_key, shadow_key, raster_key)[k])
             # What binds it is neither roofline: a closest-hit walk is a chain of dependent fetches per ray (latency), the list
             # kernels issue VALU work at a third of the lanes; the fractions against both peaks are reported all the same.
             out["roofline"] = {"kernel": kname, "bound": "latency" if k == 0 else "valu_issue", "roofline": "hbm",
@@ -502,8 +505,9 @@ def main():
                                "avg_launch_ms": round(per_launch_ms, 4), "launches_per_frame": launches_per_frame,
                                "share_of_frame": round(group_ms[k] / max(kmax[6].item(), 1e-9), 3),
                                "note": "algorithmic bytes are mostly served by L2 / Infinity Cache (the scene is %.1f MB); avg_launch_ms: HIP events, "
-                                       "one frame at a time on one stream after the timed region, kernels in the form the timed region runs "
-                                       "them but each alone on the GPU (in the timed region %d frames overlap)" % (info.device_bytes / 1e6, in_flight)}
+                                       "one frame at a time on one stream after the timed region, one kernel per launch and each alone on the GPU "
+                                       "(in the timed region %d frames overlap, and the shadow rays of a level share a launch with the closest hits "
+                                       "of the next: shadow_walk_kernel)" % (info.device_bytes / 1e6, in_flight)}
             if traffic is not None:
                 out["roofline"]["traffic_unit"] = "bytes/launch at the L2's memory side, (2*FETCH_SIZE + WRITE_SIZE) KiB, from profiles/" + traffic_src
             ach = flops_launch / (per_launch_ms * 1e-3) / 1e12

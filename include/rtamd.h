@@ -84,11 +84,12 @@ typedef struct {
     int32_t num_textures;
 } rtamd_scene_desc;
 
-#define RTAMD_PRIMARY_RAYS_AUTO 0 /* per-pass screen binning of the faces (all primary rays share the eye),
-                                     the BVH where that is cheaper                                          */
+#define RTAMD_PRIMARY_RAYS_AUTO 0 /* all primary rays share the eye: every face is projected and tested against the pixels of
+                                     its own box (the pixels keep the nearest through an atomic maximum); the BVH where
+                                     that is cheaper (many faces per pixel, or the eye inside the mesh)            */
 #define RTAMD_PRIMARY_RAYS_TREE 1 /* primary rays walk the BVH like bounce rays                            */
-#define RTAMD_PRIMARY_RAYS_BINS 2 /* screen binning whenever it is possible, also where AUTO would walk the
-                                     tree because the bins' lists come out long (small image, dense mesh)   */
+#define RTAMD_PRIMARY_RAYS_BINS 2 /* per-pass screen binning of the faces into 4x4-pixel bins, every pixel running through its
+                                     bin's list; kept whenever possible, also where the lists come out long         */
 #define RTAMD_SHADOW_RAYS_AUTO 0 /* per-sample candidate grids when every sample direction allows it   */
 #define RTAMD_SHADOW_RAYS_TREE 1 /* shadow rays walk the BVH like every other ray                       */
 
@@ -118,10 +119,10 @@ typedef struct {
 } rtamd_camera;
 
 #define RTAMD_FLAG_COUNT_WORK 1u /* also count box tests / triangle tests (slower kernels)        */
-#define RTAMD_FLAG_TIME_KERNELS 2u /* bracket every launch with HIP events on the render stream   */
-/* Frames with reflections overlap their deeper stages with the depth-0 shadow rays on two internal,
- * process-wide side streams.  A process whose streams already outnumber its hardware queues
- * (GPU_MAX_HW_QUEUES, four by default) should set this flag: everything then runs on the caller's stream. */
+#define RTAMD_FLAG_TIME_KERNELS 2u /* bracket every launch with HIP events on the render stream; such a frame runs one
+                                      kernel per launch (untimed frames pair independent stages in one launch)        */
+/* Kept for callers that set it: every frame runs on the caller's stream alone (the library has no streams of its own),
+ * so the flag changes nothing. */
 #define RTAMD_FLAG_SINGLE_STREAM 4u
 
 /* The compile-time macros of src/flyscene.hpp:22-41 and the literals of src/flyscene.cpp as
@@ -166,13 +167,14 @@ typedef struct {
     int32_t launches_trace;
     int32_t launches_shadow;
     int32_t frames;
-    float ms_raster;       /* screen-bin pass: bin count, offsets, fill and raster kernels        */
+    float ms_raster;       /* screen-space pass of the primary rays: the face raster kernel, or with forced bins the
+                            * bin count, offsets, fill and raster kernels                          */
     int32_t launches_raster; /* passes, not kernels                                               */
-    /* Last pass of the most recent frame, when it binned its faces (0 otherwise): */
+    /* Last pass of the most recent frame; the bin figures only when it binned its faces (0 otherwise): */
     uint32_t bin_entries;    /* face references in the screen bins                                */
     uint32_t bins_nonempty;  /* bins holding at least one face                                    */
-    int32_t primary_path;    /* 1: primary rays were resolved through the bins, 0: by the BVH walk
-                              * (no binning, bin buffer too small, or lists too long to pay)      */
+    int32_t primary_path;    /* 1: primary rays were resolved in screen space (face by face, or through the bins),
+                              * 0: by the BVH walk (not attempted, buffers too small, or too costly for the view) */
     int32_t bin_overflow;    /* 1: the bin buffer was too small for the view                      */
 } rtamd_stats;
 
@@ -241,11 +243,11 @@ int rtamd_host_free(void *ptr);
  * waits for the frames enqueued so far and returns the counters of the most recent call.
  * Frames in flight: the scene keeps one workspace per stream it is rendered on (sixteen at most;
  * a seventeenth stream takes over the least recently used one, after the host has waited for its last
- * frame), so frames enqueued on different streams may run at the same time -- the deeper, latency-
- * bound stages of one frame then fill the gaps of the other.  Streams overlap only while each has a
- * hardware queue of its own: the HIP runtime gives a process four unless GPU_MAX_HW_QUEUES says
- * otherwise before its first call.  A scene rendered on more than one
- * stream keeps every frame on its caller's stream, as with RTAMD_FLAG_SINGLE_STREAM. */
+ * frame), so frames enqueued on different streams may run at the same time -- the short, latency-
+ * bound launches of one frame then fill the gaps of the other.  The GPU runs about four kernels at a time
+ * however many streams feed it; streams overlap at all only while each has a hardware queue of its own,
+ * and the HIP runtime gives a process four unless GPU_MAX_HW_QUEUES says otherwise before its first call.
+ * A frame is enqueued on hip_stream and on no other stream. */
 int rtamd_render_device(rtamd_scene *scene, const rtamd_camera *cam, const rtamd_render_params *p, float *rgb_dev,
                         int32_t *face_id_dev, float *t_hit_dev, void *hip_stream);
 int rtamd_render_stats(rtamd_scene *scene, rtamd_stats *stats);

@@ -1381,112 +1381,6 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst 
     if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 2);
 }
 
-// The same pass with the lists staged through LDS.  In raster_kernel every pixel of a bin walks the bin's list on its
-// own: index, plane, vertices, one dependent fetch after the other, a dozen faces per bin and more -- forty round trips
-// to memory for a wave over the mesh, which is what the pass lasts.  Here a wave is one 8x8 tile = four bins, and its
-// 64 lanes first fetch 64 entries of the four lists (and of the big-face list) at once, whole records, one lane per
-// entry, into LDS; then every pixel runs the exact test over its own bin's share of them from LDS.  Two round trips to
-// memory per 64 candidates.  The faces a pixel tests are the same, and so is the arithmetic: same planes as raster_kernel.
-// Needs the tile's eight local rows to be eight consecutive image rows starting at a multiple of eight: the whole
-// image, or a row partition whose tiles are multiples of eight rows (the caller checks).
-template <bool COUNT>
-__global__ __launch_bounds__(256) void raster_tile_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int total_static) {
-    __shared__ float4 s_pn[4][64], s_p0[4][64], s_p1[4][64], s_p2[4][64];
-    __shared__ int2 s_range[4][64];
-    if (!bins_accepted(ws)) return;
-    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const int slot = (int)(blockIdx.x * 256 + threadIdx.x);
-    unsigned w_box = 0, w_plane = 0, w_edge = 0;
-    if (slot - lane < total_static) { // the wave's tile exists (tiles are whole: every lane has a slot)
-        int x, row;
-        const bool valid = slot_pixel(fc, slot, x, row);
-        const int gy = global_row(fc, row);
-        const int bx = x / kBinPixels, by = gy / kBinPixels;
-        // the tile's four bins: quadrant q = (lane >> 5) * 2 + ((lane >> 2) & 1), first lanes 0, 4, 32, 36.  A quadrant whose
-        // first lane lies outside the image holds no pixel at all.
-        int mine_n = 0, mine_at = 0;
-        if (valid) {
-            const int bin = by * fc.bins_x + bx;
-            mine_n = ws.bin_count[bin];
-            mine_at = ws.bin_start[bin];
-        }
-        const int nbig = ws.bin_state->num_big;
-        const int n0 = __shfl(mine_n, 0, 64), n1 = __shfl(mine_n, 4, 64), n2 = __shfl(mine_n, 32, 64), n3 = __shfl(mine_n, 36, 64);
-        const int a0 = __shfl(mine_at, 0, 64), a1 = __shfl(mine_at, 4, 64), a2 = __shfl(mine_at, 32, 64), a3 = __shfl(mine_at, 36, 64);
-        const int e1 = n0, e2 = n0 + n1, e3 = e2 + n2, total = e3 + n3; // ends of the quadrants' shares of the concatenated list
-        const int q = ((lane >> 5) << 1) | ((lane >> 2) & 1);
-        const int my_lo = q == 0 ? 0 : q == 1 ? e1 : q == 2 ? e2 : e3, my_hi = my_lo + mine_n;
-        if (COUNT && valid) ++w_box;
-        float tbest = FLT_MAX;
-        int best_tri = -2, best_rank = -1;
-        const bool shoots = valid && (mine_n + nbig > 0 || sc.num_spheres > 0);
-        if (__ballot(shoots) != 0ull) { // most tiles of most frames see no face at all: no candidates, no rays
-            const V3 o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
-            V3 d = mk(0, 0, 1);
-            if (shoots) d = primary_direction(fc, ws, x, row);
-            // intersects(): spheres first, then triangles, sharing the running maximum (:673-676)
-            if (shoots && sc.num_spheres > 0 && spheres_hit(sc, o, d, fc.t_eps, tbest)) best_tri = -1;
-            for (int c = 0; c < total + nbig; c += 64) {
-                // ---- stage entries c .. c + 63: one lane, one record
-                const int j = c + lane;
-                int idx = -1;
-                int2 range = make_int2(0, 0);
-                if (j < total) {
-                    const int at = j < e1 ? a0 + j : j < e2 ? a1 + (j - e1) : j < e3 ? a2 + (j - e2) : a3 + (j - e3);
-                    idx = ws.bin_entries[at];
-                } else if (j < total + nbig) {
-                    const int4 g = ws.big[j - total];
-                    idx = g.x;
-                    range = make_int2(g.y, g.z);
-                }
-                if (idx >= 0) {
-                    const float4 *rec = sc.tris + (size_t)idx * 4;
-                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-                    float4 r3 = rec[3];
-                    r3.w = __int_as_float(idx); // the record's spare word carries its index
-                    s_pn[wave][lane] = r0, s_p0[wave][lane] = r1, s_p1[wave][lane] = r2, s_p2[wave][lane] = r3;
-                    s_range[wave][lane] = range;
-                }
-                wave_sync();
-                // ---- every pixel: its bin's entries of this chunk, then the chunk's big faces that reach its bin
-                const int lo = max(my_lo, c) - c, hi = min(my_hi, c + 64) - c;
-                const int big_lo = max(total, c) - c, big_hi = min(total + nbig, c + 64) - c;
-                const int count = shoots ? max(hi - lo, 0) + max(big_hi - big_lo, 0) : 0;
-                for (int k = 0; k < count; ++k) {
-                    const bool listed = k < hi - lo;
-                    const int jj = listed ? lo + k : big_lo + (k - max(hi - lo, 0));
-                    if (!listed) {
-                        const int2 g = s_range[wave][jj];
-                        if (bx < (g.x & 0xffff) || bx > (g.y & 0xffff) || by < (g.x >> 16) || by > (g.y >> 16)) continue;
-                    }
-                    // exact plane + three-edge test, src/flyscene.cpp:752-789
-                    const float4 pn = s_pn[wave][jj];
-                    if (COUNT) ++w_plane;
-                    const V3 n = mk(pn.x, pn.y, pn.z);
-                    const float t = (pn.w - dot(o, n)) / dot(d, n);
-                    if (!(t >= fc.t_eps && t <= tbest)) continue; // also rejects NaN (see file header)
-                    const float4 r0 = s_p0[wave][jj], r1 = s_p1[wave][jj], r2 = s_p2[wave][jj];
-                    const int rank = __float_as_int(r1.w);
-                    if (t == tbest && rank < best_rank) continue; // equal distance: the later face wins (:760)
-                    if (COUNT) ++w_edge;
-                    const V3 v0 = mk(r0.x, r0.y, r0.z), v1 = mk(r1.x, r1.y, r1.z), v2 = mk(r2.x, r2.y, r2.z);
-                    const V3 hp = o + t * d;
-                    if (dot(cross(v1 - v0, hp - v0), n) < 0) continue;
-                    if (dot(cross(v2 - v1, hp - v1), n) < 0) continue;
-                    if (dot(cross(v0 - v2, hp - v2), n) < 0) continue;
-                    tbest = t;
-                    best_tri = __float_as_int(r2.w);
-                    best_rank = rank;
-                }
-                wave_sync();
-            }
-        }
-        ws.slot_tri[slot] = best_tri; // -2 also for the padding of an edge tile
-        if (valid) ws.slot_t[slot] = tbest;
-    }
-    if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 2);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Shadow rays through the candidate grids (shadow_grid.hpp).  All shadow rays of one light sample are
 // parallel (their direction is the sample's position, src/flyscene.cpp:884), so the faces that can occlude a
@@ -1603,122 +1497,6 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void shadow_walk_kernel(Devi
         walk_steal_body<kQueue, COUNT>(sc, fc, ws, stage + 1, depth + 1, 0, (int)blockIdx.x, walk_blocks);
     else
         shadow_grid_body<COUNT>(sc, fc, ws, stage, depth, (int)blockIdx.x - walk_blocks, (int)gridDim.x - walk_blocks);
-}
-
-// ---------------------------------------------------------------------------------------------
-// The same shadow rays with the lanes of a wave kept busy.  In shadow_grid_kernel a wave lasts as long as the longest
-// candidate list among its 64 rays while the average ray is done after one or two batches: a third of the lanes work.
-// Here a wave owns a run of `chunk` consecutive hits of one sample and hands them to its lanes as they fall idle: a
-// lane that has settled its ray (occluder found, rest of the list behind the origin, list exhausted) takes the next
-// hit of the run in the same loop iteration, so the wave runs for about (sum of the lists) / 64 iterations plus the
-// tail of its last rays instead of (longest list) per 64 rays.  The order in which rays are settled does not matter:
-// every ray writes its own byte.  Runs stay sample-major, so the waves in flight still work on one grid at a time.
-// ---------------------------------------------------------------------------------------------
-#ifndef RT_SHADOW_POOL_WAVES
-#define RT_SHADOW_POOL_WAVES 16384
-#endif
-template <bool COUNT>
-__global__ __launch_bounds__(64) void shadow_pool_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth) {
-    const int lane = (int)threadIdx.x;
-    const int nshadow = sc.num_lights * sc.spl;
-    const int nhits = ws.stage[stage].hits;
-    if (nhits <= 0) return;
-    // hits per wave: long runs amortise the tail, but the launch must still spread over the chip
-    const long long rays = (long long)nhits * nshadow;
-    int chunk = 64;
-    while (chunk < 512 && rays / (chunk * 2) >= RT_SHADOW_POOL_WAVES) chunk *= 2;
-    const int chunks = (nhits + chunk - 1) / chunk;
-    const int ngroups = chunks * nshadow;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const float *hp = ws.hits[depth & 1].p;
-    unsigned w_box = 0, w_plane = 0, w_edge = 0;
-    for (int group = (int)blockIdx.x; group < ngroups; group += (int)gridDim.x) {
-        const int sample = group / chunks, run = group - sample * chunks;
-        int next = run * chunk;
-        const int last = min(next + chunk, nhits);
-        const float4 g0 = sc.grid_headers[sample * 4 + 0], g1 = sc.grid_headers[sample * 4 + 1];
-        const float4 g2 = sc.grid_headers[sample * 4 + 2], g3 = sc.grid_headers[sample * 4 + 3];
-        const int res = __float_as_int(g3.x), first_cell = __float_as_int(g3.y);
-        const V3 d = mk(sc.samples[3 * sample], sc.samples[3 * sample + 1], sc.samples[3 * sample + 2]);
-        uint8_t *const out = ws.clear[depth & 1] + (size_t)sample * (size_t)ws.capacity;
-        int hit = -1, e = 0, end = 0;
-        float z = 0.0f;
-        V3 o = mk(0, 0, 0);
-        for (;;) {
-            // ---- idle lanes take the next hits of the run
-            const bool idle = hit < 0;
-            const unsigned long long want = __ballot(idle);
-            if (want != 0ull && next < last) {
-                const int cand = next + (int)__popcll(want & below);
-                next += (int)__popcll(want);
-                if (idle && cand < last) {
-                    hit = cand;
-                    o = mk(hp[hit], hp[(size_t)ws.capacity + hit], hp[2 * (size_t)ws.capacity + hit]);
-                    e = end = 0;
-                    float tsphere = FLT_MAX;
-                    if (sc.num_spheres > 0 && spheres_hit(sc, o, d, fc.t_eps, tsphere)) { // intersects(): spheres first (:673-676)
-                        out[hit] = 0;
-                        hit = -1;
-                    } else {
-                        // header: U (g0.xyz), V (g0.w g1.xy), W (g1.zw g2.x), u0 v0 inv_cell (g2.yzw), res first_cell (g3.xy)
-                        const float u = o.x * g0.x + (o.y * g0.y + o.z * g0.z);
-                        const float v = o.x * g0.w + (o.y * g1.x + o.z * g1.y);
-                        z = o.x * g1.z + (o.y * g1.w + o.z * g2.x);
-                        const float fx = floorf((u - g2.y) * g2.w), fy = floorf((v - g2.z) * g2.w);
-                        if (COUNT) ++w_box;
-                        if (fx >= 0.0f && fy >= 0.0f && fx < (float)res && fy < (float)res) {
-                            const int cell = first_cell + (int)fy * res + (int)fx;
-                            e = sc.grid_cells[cell], end = sc.grid_cells[cell + 1];
-                        }
-                    }
-                }
-            }
-            const bool active = hit >= 0;
-            if (__ballot(active) == 0ull) {
-                if (next >= last) break;
-                continue;
-            }
-            // ---- one batch of candidates for every lane that holds a ray
-            bool blocked = false, behind = false;
-            if (active && e < end) {
-                int2 ent[RT_SHADOW_BATCH];
-#pragma unroll
-                for (int k = 0; k < RT_SHADOW_BATCH; ++k) ent[k] = sc.grid_entries[min(e + k, end - 1)];
-                float4 pn[RT_SHADOW_BATCH];
-#pragma unroll
-                for (int k = 0; k < RT_SHADOW_BATCH; ++k) pn[k] = sc.tris[ent[k].x * 4 + 0];
-#pragma unroll
-                for (int k = 0; k < RT_SHADOW_BATCH; ++k) {
-                    if (blocked || behind || e + k >= end) continue;
-                    if (__int_as_float(ent[k].y) < z) { // this face and all later ones lie behind the origin
-                        behind = true;
-                        continue;
-                    }
-                    const int i = ent[k].x;
-                    if (COUNT) ++w_plane;
-                    const V3 n = mk(pn[k].x, pn[k].y, pn[k].z);
-                    const float t = (pn[k].w - dot(o, n)) / dot(d, n);
-                    if (!(t >= fc.t_eps && t <= FLT_MAX)) continue; // also rejects NaN (see file header)
-                    const float4 p0 = sc.tris[i * 4 + 1];
-                    const float4 p1 = sc.tris[i * 4 + 2];
-                    const float4 p2 = sc.tris[i * 4 + 3];
-                    if (COUNT) ++w_edge;
-                    const V3 v0 = mk(p0.x, p0.y, p0.z), v1 = mk(p1.x, p1.y, p1.z), v2 = mk(p2.x, p2.y, p2.z);
-                    const V3 at = o + t * d;
-                    if (dot(cross(v1 - v0, at - v0), n) < 0) continue;
-                    if (dot(cross(v2 - v1, at - v1), n) < 0) continue;
-                    if (dot(cross(v0 - v2, at - v2), n) < 0) continue;
-                    blocked = true;
-                }
-                e += RT_SHADOW_BATCH;
-            }
-            if (active && (blocked || behind || e >= end)) { // settled: the sample reaches the point unless a face blocks it
-                out[hit] = blocked ? 0 : 1;
-                hit = -1;
-            }
-        }
-    }
-    if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1940,13 +1718,6 @@ __device__ __forceinline__ void shade_body(const DeviceScene &sc, const FrameCon
         ws.stage_feedback[2 * stage + 1] = ws.stage[stage].next + 1;
     }
     const HitList hl = ws.hits[depth & 1];
-#ifdef RT_BURN
-    { // experiment: dependent multiply-adds on every lane, to see what an added VALU instruction costs a frame
-        float acc = (float)threadIdx.x;
-        for (int k = 0; k < RT_BURN; ++k) acc = __builtin_fmaf(acc, 1.0000001f, 0.5f);
-        if (acc == 12345.678f) rgb[0] = acc;
-    }
-#endif
     for (int idx = block * 256 + (int)threadIdx.x; idx < nhits; idx += nblocks * 256) {
 
     const V3 P = mk(plane(hl.p, ws.capacity, 0)[idx], plane(hl.p, ws.capacity, 1)[idx], plane(hl.p, ws.capacity, 2)[idx]);
@@ -2201,15 +1972,6 @@ void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc
         else
             bin_fill_kernel<false><<<face_blocks, 256, 0, stream>>>(sc, fc, ws, num_tris);
     }
-    // lists staged through LDS tile by tile, where a tile's rows are eight consecutive image rows from a multiple of eight
-    static const int tiled = getenv("RTAMD_RASTER_TILE") ? atoi(getenv("RTAMD_RASTER_TILE")) : 0; // experiment hook
-    if (tiled && (fc.num_parts == 1 || (fc.row_tile & 7) == 0)) {
-        if (count)
-            raster_tile_kernel<true><<<(total_static + 255) / 256, 256, 0, stream>>>(sc, fc, ws, total_static);
-        else
-            raster_tile_kernel<false><<<(total_static + 255) / 256, 256, 0, stream>>>(sc, fc, ws, total_static);
-        return;
-    }
     if (count)
         raster_kernel<true><<<(total_static + 255) / 256, 256, 0, stream>>>(sc, fc, ws, total_static);
     else
@@ -2295,14 +2057,6 @@ void launch_walk_shadow(bool count, const DeviceScene &sc, const FrameConst &fc,
     }
     const int blocks = walk_grid(groups);
     if (sc.use_grids) {
-        static const int pool = getenv("RTAMD_SHADOW_POOL") ? atoi(getenv("RTAMD_SHADOW_POOL")) : 0; // experiment hook
-        if (pool) {
-            if (count)
-                shadow_pool_kernel<true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth);
-            else
-                shadow_pool_kernel<false><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth);
-            return;
-        }
         if (count)
             shadow_grid_kernel<true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth);
         else

@@ -2,13 +2,13 @@
 # Round-end evidence for profiles/: run on the GPU box from the repository root.
 #   tools/collect_profiles.sh TAG      -> gpurun_out/profiles_TAG/
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # 1. the default bench line, and the other single-GPU workloads
-for wl in bunny_1080p bunny_1000 field_4k; do
+for wl in bunny_1080p bunny_1000 bunny_4k bunny_sub2_4k field_4k field_mirrors_8k; do
   timeout -k 10 300 python3 "$ROOT/bench.py" --workload $wl $([ $wl = bunny_1080p ] || echo --cpu-seconds 0) 2>/dev/null | tail -1 > "$OUT/bench_$wl.json" || exit 1
 done
 # 2. kernel trace of the default command (sixteen frames in flight: kernels of different frames overlap) ...
@@ -16,10 +16,11 @@ done
 export GPU_MAX_HW_QUEUES=16
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -- \
   python3 "$ROOT/bench.py" --cpu-seconds 0 > "$OUT/bench_under_rocprof_default.json" 2> "$OUT/trace_default.log" || exit 1
-# 3. ... and with every kernel alone on the GPU: these averages are the ones the roofline's avg_launch_ms must match
-# (RTAMD_FULL_WAVES=1: the kernels in the form the default command runs them; a scene rendered on one stream only
-# would spread its bounce rays over narrower waves)
-export RTAMD_FULL_WAVES=1
+# 3. ... and with every kernel alone on the GPU and one kernel per launch: these averages are the ones the roofline's
+# avg_launch_ms must match (RTAMD_FULL_WAVES=1: bounce launches in full waves as the default command runs them; a scene
+# rendered on one stream only would spread its bounce rays over narrower waves.  RTAMD_FUSE=0: the default command pairs the
+# shadow rays of a level with the closest hits of the next in one launch, which the event pass of bench.py takes apart)
+export RTAMD_FULL_WAVES=1 RTAMD_FUSE=0
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_serial" -- \
   python3 "$ROOT/bench.py" --cpu-seconds 0 --in-flight 1 --single-stream > "$OUT/bench_under_rocprof_serial.json" 2> "$OUT/trace_serial.log" || exit 1
 cd "$ROOT"

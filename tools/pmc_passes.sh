@@ -9,7 +9,7 @@ ROOT=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # kernels one at a time, but in the form the default command runs them (frames in flight keep bounce launches in full waves)
-export RTAMD_FULL_WAVES=1
+export RTAMD_FULL_WAVES=1 RTAMD_FUSE=0
 run() { # name, counters...
   local name=$1; shift
   timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$ROOT/$OUT/$name" -- \
