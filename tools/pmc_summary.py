@@ -9,8 +9,8 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ("shadow_walk_kernel", "shade_compact_kernel", "walk_steal_kernel", "walk_kernel", "shadow_grid_kernel", "shadow_pool_kernel",
-                "raster_tile_kernel", "raster_kernel", "bin_count_kernel", "bin_fill_kernel", "bin_offsets_kernel", "compact_kernel", "shade_kernel",
+    for key in ("shadow_walk_kernel", "shade_compact_kernel", "walk_steal_kernel", "walk_kernel", "shadow_grid_kernel",
+                "face_raster_kernel", "raster_kernel", "bin_count_kernel", "bin_fill_kernel", "bin_offsets_kernel", "compact_kernel", "shade_kernel",
                 "prep_kernel"):
         if key in name:
             args = name.split(key)[1].split("(")[0]
