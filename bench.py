@@ -82,8 +82,8 @@ def parse():
                     help="hardware queues asked of the HIP runtime (GPU_MAX_HW_QUEUES; 0 = leave the environment alone, and then "
                          "at most 4 frames in flight on one GPU, 2 with several)")
     ap.add_argument("--single-stream", action="store_true",
-                    help="keep every frame on its caller's stream (no side streams): with --in-flight 1 every kernel then runs alone, "
-                         "which is the mode the per-kernel profile under profiles/ is taken in")
+                    help="accepted for older command lines; frames always run entirely on their caller's stream. With --in-flight 1 (and "
+                         "RTAMD_FUSE=0 for one kernel per launch) every kernel runs alone, the mode the per-kernel profile under profiles/ is taken in")
     ap.add_argument("--force-pipeline", action="store_true",
                     help="run the several-GPU code path (gather pipeline, both payloads, single-GPU comparison) on one GPU: a rehearsal "
                          "of everything but the collective itself")
@@ -364,7 +364,7 @@ def main():
         del scratch
 
     # ---- one frame alone, as a caller with a single view gets it: a second scene object, rendered on ONE stream (the library
-    # then spreads the deeper stages of a reflective frame over its side streams and narrower waves), each frame enqueued
+    # then gives the small launches of the deeper stages narrower waves, the shortest chain on an idle chip), each frame enqueued
     # on an idle GPU and waited for; wall clock from the call to the end of the frame, and the frame's own HIP events
     fly1 = None
     single = None
