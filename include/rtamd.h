@@ -211,6 +211,14 @@ int rtamd_scene_get_info(const rtamd_scene *scene, rtamd_scene_info *info);
  * largest image and deepest recursion seen so far, plus the staging of rtamd_render.  A frame without reflections takes
  * about 40 + lights * samples_per_light bytes per pixel, one bounce about 130, deeper recursion about 210. */
 int rtamd_scene_workspace_bytes(const rtamd_scene *scene, uint64_t *bytes);
+/* Bound on the work buffers of ONE frame in flight (default 2 GiB; 0 = none).  An unpartitioned frame (num_parts == 1)
+ * whose buffers would exceed it is rendered in bands of rows, one after the other on the caller's stream through buffers
+ * of one band's size: the same image and the same counters in rtamd_stats, bit for bit (each band is rendered like one
+ * part of a partitioned frame, src/flyscene.cpp:808-809).  A 7680x4320 frame with eight lights and four bounces takes
+ * 6.7 GB whole and 1.7 GB in four bands.  Partitioned frames, and frames with so many passes that the bands would run out
+ * of stage counters (bands * ssaa^2 * (max_reflections + 1) <= 64), keep fewer bands than the bound asks for.
+ * No counterpart in the reference, whose working set per thread is a call stack. */
+int rtamd_scene_set_workspace_limit(rtamd_scene *scene, uint64_t bytes);
 
 /* Host only (no device needed): rank[f] = position of face f in the order in which the reference's
  * triangleIntersection meets the faces (leaves of boundingBox::splitBox in lower/upper preorder,

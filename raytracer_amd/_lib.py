@@ -109,6 +109,7 @@ SYMBOLS = {
     "rtamd_scene_destroy": (C.c_int, [_P]),
     "rtamd_scene_get_info": (C.c_int, [_P, C.POINTER(SceneInfo)]),
     "rtamd_scene_workspace_bytes": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "rtamd_scene_set_workspace_limit": (C.c_int, [_P, C.c_uint64]),
     "rtamd_reference_face_rank": (C.c_int, [C.POINTER(SceneDesc), _ip]),
     "rtamd_local_rows": (C.c_int32, [C.POINTER(RenderParams)]),
     "rtamd_global_row": (C.c_int32, [C.POINTER(RenderParams), C.c_int32]),

@@ -7,6 +7,7 @@
 // colour C = local + ks*LI*C_next is accumulated front to back with a running throughput.
 #include <hip/hip_runtime.h>
 
+#include <cfloat>
 #include <chrono>
 #include <mutex>
 #include <cmath>
@@ -61,7 +62,7 @@ struct TimedLaunch {
     int kind; // 0 closest-hit walk, 1 shadow walk, 2 compaction, 3 shading, 4 other, 5 whole frame, 6 screen-bin pass
 };
 
-constexpr int kMaxFrameSlots = 16;
+constexpr int kMaxFrameSlots = 32;
 constexpr int kMaxHugeFaceList = 192; // kMaxHugeFaces of kernels.hip: entries of the list the compaction kernel tests against every pixel
 // Page-locked report block of a frame slot: [0..3] what the screen binning found, [kStageFeedbackAt + 2 * stage + {0, 1}]
 // hits and spawned rays of every stage, each + 1 (0: not reported yet).
@@ -95,7 +96,7 @@ struct rtamd_scene {
     int device = -1;
     int num_cus = 256;
     void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_materials = nullptr;
-    void *d_tri_of_rank = nullptr;
+    void *d_tri_of_rank = nullptr, *d_cluster_box = nullptr;
     void *d_light_pos = nullptr, *d_samples = nullptr, *d_spheres = nullptr, *d_texels = nullptr, *d_tex_info = nullptr;
     void *d_grid_headers = nullptr, *d_grid_cells = nullptr, *d_grid_entries = nullptr;
     DeviceScene ds{};
@@ -125,6 +126,10 @@ struct rtamd_scene {
     int last_stages = 0, last_depths = 0;
     uint64_t last_primary = 0;
     hipStream_t last_stream = nullptr;
+    // A frame whose work buffers would exceed this is rendered in bands of rows, one after the other through buffers of one
+    // band's size (rtamd_scene_set_workspace_limit; 0 = never)
+    uint64_t workspace_limit = (uint64_t)2 << 30;
+    size_t open_frame_event = 0; // timing event of a banded frame, opened by its first band
     // HIP-event pairs of every launch (kind 0..4) and frame (kind 5) since the last stats call
     std::vector<TimedLaunch> events;
     size_t events_used = 0;
@@ -519,6 +524,21 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
         if (r >= 0 && r < d->num_faces) tri_of_rank[(size_t)r] = i;
     }
     if (rc == RTAMD_OK) rc = upload(&s->d_tri_of_rank, tri_of_rank, &bytes);
+    // Boxes of every 64 consecutive records (neighbours in the hierarchy, so neighbours in space): a rank that renders only
+    // some rows of the image drops whole groups of faces that lie in other ranks' rows before it touches their records.
+    std::vector<float> cluster_box((size_t)((num_records + 63) / 64) * 8, 0.0f);
+    for (int32_t c = 0; c * 64 < num_records; ++c) {
+        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int32_t i = c * 64; i < std::min(num_records, (c + 1) * 64); ++i) {
+            const TriRecord &t = bvh.tris[(size_t)i];
+            for (int k = 0; k < 3; ++k) {
+                lo[k] = std::min(lo[k], std::min(t.v0[k], std::min(t.v1[k], t.v2[k])));
+                hi[k] = std::max(hi[k], std::max(t.v0[k], std::max(t.v1[k], t.v2[k])));
+            }
+        }
+        for (int k = 0; k < 3; ++k) cluster_box[(size_t)c * 8 + k] = lo[k], cluster_box[(size_t)c * 8 + 4 + k] = hi[k];
+    }
+    if (rc == RTAMD_OK) rc = upload(&s->d_cluster_box, cluster_box, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_materials, mats, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_light_pos, lpos, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_samples, samples, &bytes);
@@ -560,6 +580,7 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     s->ds.samples = (const float *)s->d_samples;
     s->ds.spheres = (const float4 *)s->d_spheres;
     s->ds.tri_of_rank = (const int32_t *)s->d_tri_of_rank;
+    s->ds.cluster_box = (const float4 *)s->d_cluster_box;
     s->ds.texels = (const float *)s->d_texels;
     s->ds.tex_info = (const int32_t *)s->d_tex_info;
     s->ds.num_textures = textured ? d->num_textures : 0;
@@ -616,7 +637,7 @@ int rtamd_reference_face_rank(const rtamd_scene_desc *d, int32_t *rank_out) {
 
 int rtamd_scene_destroy(rtamd_scene *s) {
     if (!s) return RTAMD_OK;
-    void *bufs[] = {s->d_tri_of_rank, s->d_nodes, s->d_tris,  s->d_shade,  s->d_materials, s->d_light_pos, s->d_samples,
+    void *bufs[] = {s->d_tri_of_rank, s->d_cluster_box, s->d_nodes, s->d_tris,  s->d_shade,  s->d_materials, s->d_light_pos, s->d_samples,
                     s->d_spheres, s->d_texels, s->d_tex_info, s->d_grid_headers, s->d_grid_cells, s->d_grid_entries,
                     s->d_rgb, s->d_face};
     (void)hipDeviceSynchronize(); // frames may still be in flight on the caller's streams
@@ -669,12 +690,46 @@ int frame_shape(const rtamd_scene *s, const rtamd_render_params *p, FrameShape &
     return RTAMD_OK;
 }
 
-// Enqueues every launch of one frame on `stream` (and, for a reflective scene rendered on one caller stream, on the
-// two side streams), using the work buffers of `fs`.  `plain`: the caller may not allocate or create anything --
-// no timing events, no side streams (their events are created on demand), no completion event.
+// Rows of one band when an image of `height` rows is rendered in `bands` bands: whole 8-row tiles, the last band
+// takes what is left.
+int band_height(int height, int bands) { return ((height + bands - 1) / bands + 7) & ~7; }
+
+// In how many bands of rows a frame is rendered: one, unless the frame is an unpartitioned image whose work buffers would
+// exceed the scene's limit; then as few as bring one band's buffers under it, while the stage counters last (every band
+// takes a frame's worth of them) and every band still has rows.
+int plan_bands(const rtamd_scene *s, const rtamd_render_params *p, const FrameShape &shape) {
+    if (s->workspace_limit == 0 || p->num_parts != 1) return 1;
+    Workspace sizes{};
+    const size_t ntris = (size_t)s->info.num_device_faces;
+    const size_t bins = s->bin_primary ? (size_t)shape.bins_x * (size_t)shape.bins_y : 0;
+    const size_t whole = layout_workspace(nullptr, shape.slots, shape.nshadow, bins, ntris, s->face_primary, shape.depths, sizes);
+    if (whole <= s->workspace_limit) return 1;
+    int bands = 1;
+    const int most = std::min(kMaxStages / std::max(shape.stages, 1), (p->height + 7) / 8);
+    while (bands < most) {
+        ++bands;
+        const int rows = band_height(p->height, bands);
+        if ((size_t)(bands - 1) * (size_t)rows >= (size_t)p->height) { // the last band would be empty: not a usable count
+            continue;
+        }
+        const size_t slots = (size_t)shape.tiles_x * (size_t)((rows + 7) / 8) * 64;
+        if (layout_workspace(nullptr, slots, shape.nshadow, bins, ntris, s->face_primary, shape.depths, sizes) <= s->workspace_limit) break;
+    }
+    while (bands > 1 && (size_t)(bands - 1) * (size_t)band_height(p->height, bands) >= (size_t)p->height) --bands;
+    return bands;
+}
+
+// Enqueues every launch of one frame on `stream`, using the work buffers of `fs`.  `plain`: the caller may not
+// allocate or create anything -- no timing events, no completion event.
+// A frame rendered in bands (rtamd_render_device) comes here once per band: `p` describes the band as part `band` of
+// `bands` (row tiles of one band's height), `whole` the frame the caller asked for; the outputs point at the band's first
+// row.  Band b counts its stages from b * stages on, so that the counters of all bands add up to the frame's.
 int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const rtamd_camera *cam, const rtamd_render_params *p, float *rgb,
-                  int32_t *face_id, float *t_hit, hipStream_t stream, bool plain) {
+                  int32_t *face_id, float *t_hit, hipStream_t stream, bool plain, int band = 0, int bands = 1,
+                  const rtamd_render_params *whole = nullptr) {
     int rc = RTAMD_OK;
+    if (!whole) whole = p;
+    const int stage_base = band * shape.stages;
     const int local_rows = shape.local_rows, S = shape.S, depths = shape.depths, stages = shape.stages;
     const int tiles_x = shape.tiles_x, tiles_y = shape.tiles_y, bins_x = shape.bins_x, bins_y = shape.bins_y;
     const size_t pixels = shape.pixels, nshadow = shape.nshadow;
@@ -720,17 +775,17 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
         for (size_t i = 0; i < bytes; ++i) h = (h ^ b[i]) * 1099511628211ull; // FNV-1a
         return h;
     };
-    const int32_t shape_words[8] = {p->width, p->height, p->part, p->num_parts, p->row_tile, S, depths, (int32_t)nshadow};
+    const int32_t shape_words[9] = {p->width, p->height, whole->part, whole->num_parts, whole->row_tile, S, depths, (int32_t)nshadow, bands};
     const uint64_t size_key = mix(14695981039346656037ull, shape_words, sizeof shape_words) | 1ull;
     const uint64_t view_key = mix(size_key, cam, sizeof *cam) | 1ull;
-    std::vector<int> expect_hits((size_t)stages, -1), expect_next((size_t)stages, -1);
+    std::vector<int> expect_hits((size_t)kMaxStages, -1), expect_next((size_t)kMaxStages, -1); // by stage of the frame
     if (fs.feedback) {
         if (fs.feedback_key != size_key) {
             fs.feedback_key = size_key;
             for (int i = kStageFeedbackAt; i < kFeedbackInts; ++i) fs.feedback[i] = 0;
         }
         static const bool sized = !getenv("RTAMD_WORST_CASE_LAUNCHES"); // experiment hook
-        for (int i = 0; sized && i < stages; ++i) {
+        for (int i = stage_base; sized && i < stage_base + stages; ++i) {
             expect_hits[(size_t)i] = fs.feedback[kStageFeedbackAt + 2 * i] - 1;
             expect_next[(size_t)i] = fs.feedback[kStageFeedbackAt + 2 * i + 1] - 1;
         }
@@ -809,10 +864,9 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
         HIP_TRY(hipEventRecord(s->events[open_slot].stop, stream));
         return RTAMD_OK;
     };
-    size_t frame_slot = 0;
-    if (timed) {
+    if (timed && band == 0) {
         if ((rc = begin(5)) != RTAMD_OK) return rc;
-        frame_slot = open_slot;
+        s->open_frame_event = open_slot;
     }
 
     // Per SSAA pass the work of depth d is walk(d) -> compact(d) (which also spawns the rays of depth d+1) ->
@@ -833,13 +887,13 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
     // and puts the zero back, and a fresh workspace is cleared when it is allocated.  Only the array shared by all callers
     // of the allocation-free entry point may hold anything.
     const size_t key_clear = faces_ok && plain ? pixels * sizeof(unsigned long long) : 0;
-    int stage = 0;
+    int stage = stage_base;
     for (int xs = 0; xs < S; ++xs)
         for (int ys = 0; ys < S; ++ys) {
             fc.sub_x = (float)xs / S; // src/flyscene.cpp:816-817
             fc.sub_y = (float)ys / S;
             fc.accumulate = (xs | ys) != 0;
-            if (stage == 0)
+            if (stage == 0) // (the first pass of the first band)
                 launch_prep(fc, ws_frame, fs.block, 4096 + bin_clear, ws_frame.pix_key, key_clear, stream);
             else
                 launch_prep(fc, ws_frame, (char *)fs.block + 4096, bin_clear, ws_frame.pix_key, key_clear, stream);
@@ -902,15 +956,15 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
         launch_scale(rgb, pixels * 3, (float)(S * S), stream);
         if ((rc = end()) != RTAMD_OK) return rc;
     }
-    if (timed) HIP_TRY(hipEventRecord(s->events[frame_slot].stop, stream));
-    if (fs.done) HIP_TRY(hipEventRecord(fs.done, stream));
+    if (timed && band == bands - 1) HIP_TRY(hipEventRecord(s->events[s->open_frame_event].stop, stream));
+    if (fs.done && band == bands - 1) HIP_TRY(hipEventRecord(fs.done, stream));
     fs.used = true;
     HIP_TRY(hipGetLastError());
 
-    s->last = *p;
-    s->last_stages = stages;
+    s->last = *whole;
+    s->last_stages = stage_base + stages;
     s->last_depths = depths;
-    s->last_primary = (uint64_t)pixels * (uint64_t)(S * S);
+    s->last_primary = (band ? s->last_primary : 0) + (uint64_t)pixels * (uint64_t)(S * S);
     s->last_stream = stream;
     s->last_frame_slot = &fs;
     s->have_frame = true;
@@ -936,9 +990,30 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     if (shape.pixels == 0) return RTAMD_OK;
     FrameSlot *slot = nullptr;
     if ((rc = acquire_slot(s, stream, &slot)) != RTAMD_OK) return rc;
-    rc = ensure_workspace(s, *slot, shape.slots, (size_t)shape.bins_x * (size_t)shape.bins_y, shape.depths);
+    const int bands = plan_bands(s, p, shape);
+    if (bands == 1) {
+        rc = ensure_workspace(s, *slot, shape.slots, (size_t)shape.bins_x * (size_t)shape.bins_y, shape.depths);
+        if (rc != RTAMD_OK) return rc;
+        return enqueue_frame(s, *slot, shape, cam, p, rgb, face_id, t_hit, stream, /*plain=*/false);
+    }
+    // In bands: band b is part b of `bands` under row tiles of one band's height, i.e. the image's rows
+    // [b * band_rows, (b + 1) * band_rows), rendered like one rank's share of a partitioned frame and written where those
+    // rows lie in the caller's planes.  The bands follow each other on the stream through the same work buffers.
+    rtamd_render_params pb = *p;
+    pb.row_tile = band_height(p->height, bands), pb.num_parts = bands, pb.part = 0;
+    FrameShape band_shape;
+    if ((rc = frame_shape(s, &pb, band_shape)) != RTAMD_OK) return rc;
+    rc = ensure_workspace(s, *slot, band_shape.slots, (size_t)band_shape.bins_x * (size_t)band_shape.bins_y, band_shape.depths);
     if (rc != RTAMD_OK) return rc;
-    return enqueue_frame(s, *slot, shape, cam, p, rgb, face_id, t_hit, stream, /*plain=*/false);
+    for (int b = 0; b < bands; ++b) {
+        pb.part = b;
+        if ((rc = frame_shape(s, &pb, band_shape)) != RTAMD_OK) return rc;
+        const size_t at = (size_t)b * (size_t)pb.row_tile * (size_t)p->width; // first pixel of the band
+        rc = enqueue_frame(s, *slot, band_shape, cam, &pb, rgb + 3 * at, face_id ? face_id + at : nullptr, t_hit ? t_hit + at : nullptr, stream,
+                           /*plain=*/false, b, bands, p);
+        if (rc != RTAMD_OK) return rc;
+    }
+    return RTAMD_OK;
 }
 
 int rtamd_render_device_noalloc(rtamd_scene *s, const rtamd_camera *cam, const rtamd_render_params *p, float *rgb, int32_t *face_id,
@@ -975,6 +1050,12 @@ int rtamd_render_device_noalloc(rtamd_scene *s, const rtamd_camera *cam, const r
     return enqueue_frame(s, fs, shape, cam, p, rgb, face_id, t_hit, (hipStream_t)hip_stream, /*plain=*/true);
 }
 
+
+int rtamd_scene_set_workspace_limit(rtamd_scene *s, uint64_t bytes) {
+    if (!s) return fail(RTAMD_ERR_INVALID, "null scene");
+    s->workspace_limit = bytes;
+    return RTAMD_OK;
+}
 
 int rtamd_scene_workspace_bytes(const rtamd_scene *s, uint64_t *bytes) {
     if (!s || !bytes) return fail(RTAMD_ERR_INVALID, "null scene or output");

@@ -123,6 +123,16 @@ __device__ __forceinline__ bool slot_pixel(const FrameConst &fc, int slot, int &
     return x < fc.width && row < fc.local_rows;
 }
 
+// The same for a wave whose lanes hold 64 consecutive slots starting at a multiple of 64, all lanes active: the tile is
+// the wave's, so its division runs once on the scalar unit instead of in every lane.
+__device__ __forceinline__ bool slot_pixel_of_wave(const FrameConst &fc, int slot, int &x, int &row) {
+    const int tile = __builtin_amdgcn_readfirstlane(slot >> 6), in = slot & 63;
+    const int ty = (int)fast_div((unsigned)tile, (unsigned)fc.tiles_x, fc.tiles_x_magic), tx = tile - ty * fc.tiles_x;
+    x = tx * 8 + (in & 7);
+    row = ty * 8 + (in >> 3);
+    return x < fc.width && row < fc.local_rows;
+}
+
 // Direction of the primary ray of pixel (x, local row): camera_direction with the two screen coordinates -- which
 // depend on the column alone and on the row alone -- read from the tables that prep_kernel filled for this pass
 // with camera_direction's own expressions (double-precision divisions once per column and row, not per pixel).
@@ -1179,6 +1189,9 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(DeviceScene sc, FrameCons
 // kHugePixels (or is unbounded: a corner beside or behind the eye) go to the list that the compaction kernel tests
 // against every pixel; when that list grows long (the eye inside a dense mesh) the pass gives way to the tree walk.
 // ---------------------------------------------------------------------------------------------
+#ifndef RT_CLUSTER_CULL
+#define RT_CLUSTER_CULL(fc) ((fc).num_parts > 1)
+#endif
 constexpr int kHugePixels = 16384; // a face with a larger pixel box is tested pixel by pixel in the compaction kernel
 constexpr int kDirectPairs = 8;    // waves whose faces all have at most this many pixels skip the dealing
 
@@ -1192,6 +1205,51 @@ __device__ __forceinline__ bool local_row_of(const FrameConst &fc, int gy, int &
     const int lt = (int)fast_div((unsigned)tile, (unsigned)fc.num_parts, fc.num_parts_magic);
     if (tile - lt * fc.num_parts != fc.part) return false;
     lr = lt * fc.row_tile + (gy - tile * fc.row_tile);
+    return true;
+}
+
+// Can this part skip the 64 faces of record group `cluster` without looking at them?  Yes when the group's box lies wholly
+// in front of the eye and the rows its projection covers all belong to other parts (or none is on the screen): the
+// projection of a convex body in front of the eye plane lies inside the hull of its projected corners, so every face of
+// the group would find the same in its own test in face_raster_kernel.  Every lane of the wave must call this; the
+// eight corners are projected by lanes 0..7 of every group of eight, and all lanes return the same answer.
+// Rounding: with the depth of every corner at least a fiftieth of its reach, a projected corner is within a quarter of a
+// pixel of its true position at 8K (the bound at RT_BIN_MARGIN with R / s <= 50) and within 0.9 pixel at the largest
+// image the face pass takes; the rows are widened by the margin and two pixels.
+__device__ __forceinline__ bool cluster_outside_part(const DeviceScene &sc, const FrameConst &fc, int cluster, int lane) {
+    const float4 lo = sc.cluster_box[2 * cluster], hi = sc.cluster_box[2 * cluster + 1];
+    const V3 p = mk((lane & 1) ? hi.x : lo.x, (lane & 2) ? hi.y : lo.y, (lane & 4) ? hi.z : lo.z);
+    const V3 r = p - mk(fc.origin[0], fc.origin[1], fc.origin[2]);
+    const float *m = fc.lin_inv;
+    const float qx = m[0] * r.x + (m[1] * r.y + m[2] * r.z);
+    const float qy = m[3] * r.x + (m[4] * r.y + m[5] * r.z);
+    const float qz = m[6] * r.x + (m[7] * r.y + m[8] * r.z);
+    const float s = qz / (fc.cam_e[2] - 1.0f); // as in project_point
+    const float reach = fabsf(qx) + fabsf(qy) + fabsf(qz);
+    float smin = s, rmax = reach;
+    for (int off = 1; off < 8; off <<= 1) smin = fminf(smin, __shfl_xor(smin, off, 64)), rmax = fmaxf(rmax, __shfl_xor(rmax, off, 64));
+    if (!(smin > 0.02f * rmax)) return false; // a corner near or behind the eye plane (or not a number): no verdict
+    const float nx = qx / s - fc.cam_e[0], ny = qy / s - fc.cam_e[1];
+    const float px = fc.vp[0] + (nx / fc.ax + 1.0f) * (0.5f * fc.vp[2]);
+    const float py = fc.vp[1] + (1.0f - ny / fc.scale) * (0.5f * fc.vp[3]);
+    float xlo = px, xhi = px, ylo = py, yhi = py;
+    for (int off = 1; off < 8; off <<= 1) {
+        xlo = fminf(xlo, __shfl_xor(xlo, off, 64)), xhi = fmaxf(xhi, __shfl_xor(xhi, off, 64));
+        ylo = fminf(ylo, __shfl_xor(ylo, off, 64)), yhi = fmaxf(yhi, __shfl_xor(yhi, off, 64));
+    }
+    const float lim = 1e6f;
+    if (!(fabsf(xlo) < lim && fabsf(xhi) < lim && fabsf(ylo) < lim && fabsf(yhi) < lim)) return false; // (also: not a number)
+    const float slack = fc.raster_margin + 2.0f;
+    const float fx0 = fmaxf(ceilf(xlo - slack - fc.sub_x), 0.0f), fy0 = fmaxf(ceilf(ylo - slack - fc.sub_y), 0.0f);
+    const float fx1 = fminf(floorf(xhi + slack - fc.sub_x), (float)(fc.width - 1)), fy1 = fminf(floorf(yhi + slack - fc.sub_y), (float)(fc.height - 1));
+    if (fx0 > fx1 || fy0 > fy1) return true; // off the screen
+    const int t0 = (int)fast_div((unsigned)(int)fy0, (unsigned)fc.row_tile, fc.row_tile_magic);
+    const int t1 = (int)fast_div((unsigned)(int)fy1, (unsigned)fc.row_tile, fc.row_tile_magic);
+    if (t1 - t0 + 1 >= fc.num_parts) return false;
+    for (int t = t0; t <= t1; ++t) {
+        const int lt = (int)fast_div((unsigned)t, (unsigned)fc.num_parts, fc.num_parts_magic);
+        if (t - lt * fc.num_parts == fc.part) return false;
+    }
     return true;
 }
 
@@ -1230,7 +1288,11 @@ __global__ __launch_bounds__(256) void face_raster_kernel(DeviceScene sc, FrameC
     unsigned w_box = 0, w_plane = 0, w_edge = 0;
     ProjectedFace f;
     f.empty = true, f.unbounded = false, f.px0 = f.py0 = 0, f.px1 = f.py1 = -1;
-    if (tri < num_tris) f = project_face(sc, fc, tri);
+    // a rank that renders some rows only: groups of faces that lie in other ranks' rows are dropped unseen
+    bool skip = false;
+    if (RT_CLUSTER_CULL(fc) && (int)(blockIdx.x * 256) + wave * 64 < num_tris)
+        skip = cluster_outside_part(sc, fc, (int)(blockIdx.x * 4) + wave, lane);
+    if (tri < num_tris && !skip) f = project_face(sc, fc, tri);
     if (COUNT && tri < num_tris) ++w_box;
     int w = f.px1 - f.px0 + 1, h = f.py1 - f.py0 + 1;
     if (!f.empty && fc.num_parts > 1) { // rows of other parts only?  (a small face lies in one or two row tiles)
@@ -1395,6 +1457,9 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst 
 #ifndef RT_SHADOW_BATCH
 #define RT_SHADOW_BATCH 3
 #endif
+#ifndef RT_SHADOW_XCD
+#define RT_SHADOW_XCD 1
+#endif
 template <bool COUNT>
 __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, int block, int nblocks) {
     const int lane = (int)threadIdx.x;
@@ -1410,8 +1475,23 @@ __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const Fr
     const int chunks = (nhits + (1 << per_wave_shift) - 1) >> per_wave_shift;
     const int ngroups = chunks * nshadow;
     unsigned w_box = 0, w_plane = 0, w_edge = 0;
-    for (int group = block; group < ngroups; group += nblocks) {
-        // sample-major: the waves in flight at one time work on one grid, not on all of them (8 lights at 8K: -12 %)
+    // Workgroups b and b + 8 run on the same XCD and share its 4 MiB L2.  Dealt out in launch order, every XCD would see
+    // every eighth group of every sample, fetch the lines that neighbouring groups share once per XCD, and stream all
+    // grids past its L2.  Instead the XCD class of a workgroup (b & 7) takes runs of consecutive groups of the
+    // sample-major sequence.  With a dozen samples or more the run is a whole eighth of the sequence: the grids of one or
+    // two samples, which the L2 holds while the class works through them row of tiles after row of tiles (1080p bunny, 13
+    // samples: shadow launches 6 % shorter, frames in flight 3 % faster).  With fewer samples an eighth is a band of the
+    // image or a single light, whose costs differ too much for one launch to balance (1.1 M-face field at 4K, one
+    // sample: 5 % slower); runs of 64 groups keep the lines shared by neighbours and the balance (1 % faster).
+    const bool by_xcd = RT_SHADOW_XCD != 0 && (nblocks & 7) == 0;
+    const int run = nshadow >= 12 ? max((ngroups + 7) >> 3, 1) : 64;
+    const int per_xcd = ((ngroups + 8 * run - 1) / (8 * run)) * run;
+    for (int g = block; by_xcd ? (g >> 3) < per_xcd : g < ngroups; g += nblocks) {
+        const int j = g >> 3, turn = j / run;
+        const int group = by_xcd ? turn * (8 * run) + (g & 7) * run + (j - turn * run) : g;
+        if (group >= ngroups) continue;
+        // sample-major: the waves in flight at one time work on one grid, not on all of them (8 lights at 8K: -12 %; the
+        // thirteen samples of a soft shadow, whose candidates overlap, gain nothing from hit-major order either)
         const int sample = group / chunks, chunk = group - sample * chunks;
         const int hit = (chunk << per_wave_shift) + (lane >> split_shift);
         const bool valid = hit < nhits;
@@ -1533,7 +1613,7 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
         const int slot = first + j * 256 + tid;
         bool valid = slot < total;
         int x = 0, row = 0;
-        if (PRIMARY && valid) valid = slot_pixel(fc, slot, x, row);
+        if (PRIMARY) valid = slot_pixel_of_wave(fc, slot, x, row) && valid; // (`first` and the segments are multiples of 256)
         int tri = -2;
         float t_found = 0.0f;
         if (PRIMARY && from_keys) {
@@ -1543,7 +1623,7 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
             if (valid) {
                 float tbest = FLT_MAX;
                 int best_rank = -1;
-                unsigned long long *const cell = ws.pix_key + ((size_t)row * (size_t)fc.width + (size_t)x);
+                unsigned long long *const cell = ws.pix_key + (row * fc.width + x); // (a frame's pixels fit 31 bits: frame_shape)
                 const unsigned long long held = *cell;
                 if (held != 0ull) {
                     *cell = 0ull; // every pixel's key is read exactly once per pass: left clean for the next one
@@ -1637,7 +1717,7 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
         int pix = 0;
         if (PRIMARY) {
             int x = 0, row = 0;
-            const bool valid = slot < total && slot_pixel(fc, slot, x, row);
+            const bool valid = slot_pixel_of_wave(fc, slot, x, row) && slot < total;
             pix = row * fc.width + x;
             if (valid) {
                 if (face_id) face_id[pix] = tri >= 0 ? __float_as_int(sc.tris[tri * 4 + 1].w) : tri;
@@ -2055,7 +2135,7 @@ void launch_walk_shadow(bool count, const DeviceScene &sc, const FrameConst &fc,
         const bool split = sc.use_grids && hits * nshadow < RT_SHADOW_SPLIT_BELOW;
         groups = std::min(groups, (split ? (hits + 3) / 4 : (hits + 63) / 64) * nshadow);
     }
-    const int blocks = walk_grid(groups);
+    const int blocks = sc.use_grids ? (walk_grid(groups) + 7) & ~7 : walk_grid(groups); // (whole rounds over the XCDs: shadow_grid_body)
     if (sc.use_grids) {
         if (count)
             shadow_grid_kernel<true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth);
@@ -2103,7 +2183,8 @@ bool can_fuse_shade_compact(const Workspace &ws) { return ws.capacity <= (4 << 2
 
 void launch_shadow_walk(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, int expect_hits,
                         int expect_next, hipStream_t stream) {
-    const int wblocks = bounce_walk_blocks(ws, expect_next), sblocks = shadow_blocks(sc, fc, expect_hits);
+    // both shares in whole rounds over the eight XCDs, so that a shadow workgroup's index within its share tells its XCD class
+    const int wblocks = (bounce_walk_blocks(ws, expect_next) + 7) & ~7, sblocks = (shadow_blocks(sc, fc, expect_hits) + 7) & ~7;
     if (count)
         shadow_walk_kernel<true><<<wblocks + sblocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, wblocks);
     else

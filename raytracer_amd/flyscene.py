@@ -212,6 +212,10 @@ class Flyscene:
         L.check(self.lib.rtamd_scene_workspace_bytes(self.scene, C.byref(n)), "rtamd_scene_workspace_bytes")
         return n.value
 
+    def set_workspace_limit(self, nbytes):
+        """Frames whose work buffers would exceed `nbytes` are rendered in bands of rows (0: never)."""
+        L.check(self.lib.rtamd_scene_set_workspace_limit(self.scene, C.c_uint64(int(nbytes))), "rtamd_scene_set_workspace_limit")
+
     def info(self):
         i = L.SceneInfo()
         L.check(self.lib.rtamd_scene_get_info(self.scene, C.byref(i)), "rtamd_scene_get_info")

@@ -521,6 +521,53 @@ def test_row_tile_parts_assemble_to_the_full_frame(parts, tile):
     assert np.array_equal(ids.cpu().numpy(), full["face_id"])
 
 
+@pytest.mark.parametrize("name,size,kw", [("reflect_test", (200, 203), dict(max_reflections=3)),
+                                          ("toy", (96, 100), dict(ssaa_level=2, max_reflections=1)),
+                                          ("bunny", (333, 222), dict(max_reflections=0))])
+def test_frames_rendered_in_bands_equal_whole_frames(name, size, kw):
+    """rtamd_scene_set_workspace_limit: a frame rendered band by band through work buffers of one band's size is the whole
+    frame bit for bit, ray counts included, through both entry points and again once the launches are sized by feedback."""
+    import torch
+
+    W, H = size
+    whole, _ = make_pair(name, width=W, height=H)
+    banded, _ = make_pair(name, width=W, height=H)
+    whole.set_params(**kw)
+    banded.set_params(**kw)
+    whole.set_workspace_limit(0)
+
+    def frame(fly, **pk):
+        rgb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        fid = torch.full((H, W), -7, dtype=torch.int32, device="cuda")
+        t = torch.zeros((H, W), dtype=torch.float32, device="cuda")
+        fly.render_device(rgb, fid, t, params=fly.params_copy(**pk) if pk else None)
+        torch.cuda.synchronize()
+        st = fly.stats()
+        return rgb.cpu().numpy().view(np.uint32), fid.cpu().numpy(), t.cpu().numpy().view(np.uint32), st
+
+    ref = frame(whole)
+    banded.set_workspace_limit(whole.workspace_bytes() // 5)
+    for _ in range(3):
+        got = frame(banded)
+        for a, b in zip(ref[:3], got[:3]):
+            assert np.array_equal(a, b)
+        for field in ("rays_primary", "hits", "rays_shadow", "rays_bounce"):
+            assert getattr(ref[3], field) == getattr(got[3], field), field
+    assert banded.workspace_bytes() < whole.workspace_bytes() // 2
+    host = banded.render()
+    assert np.array_equal(host["rgb"].view(np.uint32), ref[0]) and np.array_equal(host["face_id"], ref[1])
+    assert host["stats"].rays_shadow == ref[3].rays_shadow and host["stats"].rays_bounce == ref[3].rays_bounce
+    # a frame timed kernel by kernel is still one frame, whatever the number of bands
+    timed = frame(banded, flags=L.FLAG_TIME_KERNELS)
+    assert np.array_equal(timed[0], ref[0]) and timed[3].frames == 1 and timed[3].ms_frames > 0
+    # the tree walk for the primary rays, band by band
+    tree, _ = make_pair(name, width=W, height=H, primary_rays=L.PRIMARY_RAYS_TREE)
+    tree.set_params(**kw)
+    tree.set_workspace_limit(whole.workspace_bytes() // 5)
+    got = frame(tree)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[3].rays_bounce == ref[3].rays_bounce
+
+
 def test_device_ppm_quantisation_matches_the_file_writer(tmp_path):
     """rtamd_quantize_ppm gives the bytes of the reference's writePPMImage (utils/ppmIO.hpp:203), also at channel
     values of exactly k/255, above 1, and for lengths that are no multiple of four."""
