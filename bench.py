@@ -78,8 +78,11 @@ def parse():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="frames enqueued at a time, each on a stream of its own (1..32; default: 4 on one GPU -- the GPU runs four "
                          "kernels at a time, one per hardware pipe, and eight or sixteen frames in flight are no faster in the steady "
-                         "state and slower over a short batch -- 8 per rank with several; fewer when the frames' workspaces would "
-                         "take more than 64 GB)")
+                         "state and slower over a short batch, on one GPU and for one rank's share of a frame alike; fewer when the "
+                         "frames' workspaces would take more than 64 GB)")
+    ap.add_argument("--pipeline-depth", type=int, default=8,
+                    help="several GPUs: frame buffers of the gather pipeline (at least the frames in flight); the gather of a frame may "
+                         "lag that many frames behind its tracing")
     ap.add_argument("--hw-queues", type=int, default=16,
                     help="hardware queues asked of the HIP runtime (GPU_MAX_HW_QUEUES; 0 = leave the environment alone, and then "
                          "at most 4 frames in flight on one GPU, 2 with several)")
@@ -278,7 +281,7 @@ def main():
     ns = len(w["lights"]) * (1 + w["soft_points"])
     per_slot = 48 + ns if w["max_reflections"] == 0 else (112 if w["max_reflections"] == 1 else 192) + 2 * ns
     slot_bytes = (W * ((H + world - 1) // world)) * per_slot
-    in_flight = max(1, min(a.in_flight or (8 if piped else 4), 32, max(1, queues - 2) if piped else (32 if queues >= 16 else max(4, queues)),
+    in_flight = max(1, min(a.in_flight or 4, 32, max(1, queues - 2) if piped else (32 if queues >= 16 else max(4, queues)),
                            max(2, int(64e9 // max(slot_bytes, 1)))))
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(in_flight - 1)]
     turn = [0]
@@ -299,7 +302,7 @@ def main():
         # every rank with the file writer's expression (a quarter of the float framebuffer's bytes); --gather f32
         # sends the floats instead.
         def make_pipeline(as_bytes):
-            pipe = tiles.GatherPipeline(mine, W, 3, dev, dtype=torch.uint8 if as_bytes else torch.float32, depth=in_flight,
+            pipe = tiles.GatherPipeline(mine, W, 3, dev, dtype=torch.uint8 if as_bytes else torch.float32, depth=max(in_flight, a.pipeline_depth),
                                         rehearse=not use_dist, collective_alone=use_dist)
             bufs = [torch.zeros((max(rows, 1), W, 3), dtype=torch.float32, device=dev) for _ in range(in_flight)] if as_bytes else None
 

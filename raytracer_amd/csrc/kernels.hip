@@ -1195,19 +1195,6 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(DeviceScene sc, FrameCons
 constexpr int kHugePixels = 16384; // a face with a larger pixel box is tested pixel by pixel in the compaction kernel
 constexpr int kDirectPairs = 8;    // waves whose faces all have at most this many pixels skip the dealing
 
-// Local (packed) row of image row gy under the row-tile partition; false: another part renders that row.
-__device__ __forceinline__ bool local_row_of(const FrameConst &fc, int gy, int &lr) {
-    if (fc.num_parts == 1) {
-        lr = gy;
-        return true;
-    }
-    const int tile = (int)fast_div((unsigned)gy, (unsigned)fc.row_tile, fc.row_tile_magic);
-    const int lt = (int)fast_div((unsigned)tile, (unsigned)fc.num_parts, fc.num_parts_magic);
-    if (tile - lt * fc.num_parts != fc.part) return false;
-    lr = lt * fc.row_tile + (gy - tile * fc.row_tile);
-    return true;
-}
-
 // Can this part skip the 64 faces of record group `cluster` without looking at them?  Yes when the group's box lies wholly
 // in front of the eye and the rows its projection covers all belong to other parts (or none is on the screen): the
 // projection of a convex body in front of the eye plane lies inside the hull of its projected corners, so every face of
@@ -1253,12 +1240,20 @@ __device__ __forceinline__ bool cluster_outside_part(const DeviceScene &sc, cons
     return true;
 }
 
-// One (face, pixel) pair: the exact plane + three-edge test of src/flyscene.cpp:752-789 for the pixel's primary ray.
+// Number of this part's rows among the image rows [0, y): the local row of image row y if the part renders it.
+__device__ __forceinline__ int local_rows_below(const FrameConst &fc, int y) {
+    if (fc.num_parts == 1) return y;
+    const int tile = (int)fast_div((unsigned)y, (unsigned)fc.row_tile, fc.row_tile_magic);
+    const int turn = (int)fast_div((unsigned)tile, (unsigned)fc.num_parts, fc.num_parts_magic);
+    const int who = tile - turn * fc.num_parts;
+    return turn * fc.row_tile + (who > fc.part ? fc.row_tile : who == fc.part ? y - tile * fc.row_tile : 0);
+}
+
+// One (face, pixel) pair: the exact plane + three-edge test of src/flyscene.cpp:752-789 for the primary ray of the pixel in
+// column x of LOCAL row lr.
 template <bool COUNT>
-__device__ __forceinline__ void raster_pair(const FrameConst &fc, const Workspace &ws, float4 pn, float4 r0, float4 r1, float4 r2, int x, int gy,
+__device__ __forceinline__ void raster_pair(const FrameConst &fc, const Workspace &ws, float4 pn, float4 r0, float4 r1, float4 r2, int x, int lr,
                                             unsigned &w_plane, unsigned &w_edge) {
-    int lr;
-    if (!local_row_of(fc, gy, lr)) return;
     const V3 o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
     const V3 d = primary_direction(fc, ws, x, lr);
     unsigned long long *const cell = ws.pix_key + ((size_t)lr * (size_t)fc.width + (size_t)x);
@@ -1293,19 +1288,18 @@ __global__ __launch_bounds__(256) void face_raster_kernel(DeviceScene sc, FrameC
     if (RT_CLUSTER_CULL(fc) && (int)(blockIdx.x * 256) + wave * 64 < num_tris)
         skip = cluster_outside_part(sc, fc, (int)(blockIdx.x * 4) + wave, lane);
     if (tri < num_tris && !skip) f = project_face(sc, fc, tri);
-    if (COUNT && tri < num_tris) ++w_box;
+    if (COUNT && tri < num_tris && !skip) ++w_box; // faces projected
     int w = f.px1 - f.px0 + 1, h = f.py1 - f.py0 + 1;
-    if (!f.empty && fc.num_parts > 1) { // rows of other parts only?  (a small face lies in one or two row tiles)
-        const int t0 = (int)fast_div((unsigned)f.py0, (unsigned)fc.row_tile, fc.row_tile_magic);
-        const int t1 = (int)fast_div((unsigned)f.py1, (unsigned)fc.row_tile, fc.row_tile_magic);
-        bool mine = t1 - t0 + 1 >= fc.num_parts;
-        for (int t = t0; !mine && t <= t1; ++t) {
-            const int lt = (int)fast_div((unsigned)t, (unsigned)fc.num_parts, fc.num_parts_magic);
-            mine = t - lt * fc.num_parts == fc.part;
-        }
-        if (!mine) f.empty = true;
+    const bool large = f.unbounded || w * h > kHugePixels;
+    // From here on the box's rows are this part's own (packed) rows: a face that spans the row tiles of several parts is
+    // tested against the rows rendered here only, and one that touches none of them is dropped.
+    int row0 = f.py0;
+    if (!f.empty && fc.num_parts > 1) {
+        row0 = local_rows_below(fc, f.py0);
+        h = local_rows_below(fc, f.py1 + 1) - row0;
+        if (h <= 0) f.empty = true;
     }
-    const bool huge = !f.empty && (f.unbounded || w * h > kHugePixels);
+    const bool huge = !f.empty && large;
     if (huge) {
         const int at = atomicAdd(&ws.bin_state->num_big, 1);
         if (at < kMaxHugeFaces) ws.big[at] = make_int4(tri, f.px0 | (f.py0 << 16), f.px1 | (f.py1 << 16), 0);
@@ -1318,14 +1312,14 @@ __global__ __launch_bounds__(256) void face_raster_kernel(DeviceScene sc, FrameC
         const float4 r1 = sc.tris[(size_t)min(tri, num_tris - 1) * 4 + 2], r2 = sc.tris[(size_t)min(tri, num_tris - 1) * 4 + 3];
         if (most <= kDirectPairs) {
             // every lane its own face: k-th pixel of the box, row by row
-            int x = f.px0, y = f.py0;
+            int x = f.px0, y = row0;
             for (int k = 0; k < most; ++k) {
                 if (k < count) raster_pair<COUNT>(fc, ws, pn, r0, r1, r2, x, y, w_plane, w_edge);
                 if (++x > f.px1) x = f.px0, ++y;
             }
         } else {
             s_rec[wave][0][lane] = pn, s_rec[wave][1][lane] = r0, s_rec[wave][2][lane] = r1, s_rec[wave][3][lane] = r2;
-            s_box[wave][lane] = make_int4(f.px0, f.py0, max(w, 1), (int)(w <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / (unsigned long long)w)));
+            s_box[wave][lane] = make_int4(f.px0, row0, max(w, 1), (int)(w <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / (unsigned long long)w)));
             int incl = count; // inclusive scan of the counts over the wave
             for (int dlt = 1; dlt < 64; dlt <<= 1) {
                 const int up = __shfl_up(incl, dlt, 64);
