@@ -249,13 +249,14 @@ int rtamd_host_free(void *ptr);
  * synchronisation; outputs are DEVICE pointers on the scene's device (face_id, t_hit may be NULL;
  * t_hit = local_rows*width floats, primary hit distance, 0 on a miss).  rtamd_render_stats()
  * waits for the frames enqueued so far and returns the counters of the most recent call.
- * Frames in flight: the scene keeps one workspace per stream it is rendered on (sixteen at most;
- * a seventeenth stream takes over the least recently used one, after the host has waited for its last
+ * Frames in flight: the scene keeps one workspace per stream it is rendered on (thirty-two at most;
+ * one stream more takes over the least recently used one, after the host has waited for its last
  * frame), so frames enqueued on different streams may run at the same time -- the short, latency-
- * bound launches of one frame then fill the gaps of the other.  The GPU runs about four kernels at a time
- * however many streams feed it; streams overlap at all only while each has a hardware queue of its own,
- * and the HIP runtime gives a process four unless GPU_MAX_HW_QUEUES says otherwise before its first call.
- * A frame is enqueued on hip_stream and on no other stream. */
+ * bound launches of one frame then fill the gaps of the other.  The GPU runs four kernels at a time
+ * however many streams feed it: FOUR streams, frame k on stream k mod 4, reach the full rate (eight or sixteen
+ * are no faster and hold that many workspaces; five or six are slower).  Streams overlap at all only while each
+ * has a hardware queue of its own; the HIP runtime gives a process four unless GPU_MAX_HW_QUEUES says otherwise
+ * before its first call.  A frame is enqueued on hip_stream and on no other stream. */
 int rtamd_render_device(rtamd_scene *scene, const rtamd_camera *cam, const rtamd_render_params *p, float *rgb_dev,
                         int32_t *face_id_dev, float *t_hit_dev, void *hip_stream);
 int rtamd_render_stats(rtamd_scene *scene, rtamd_stats *stats);
@@ -267,9 +268,9 @@ int rtamd_render_stats(rtamd_scene *scene, rtamd_stats *stats);
  * that much until the process ends -- so the call allocates, frees and creates nothing: no hipMalloc, no events,
  * no internal streams (everything is enqueued on hip_stream; RTAMD_FLAG_TIME_KERNELS is ignored).  The array's
  * address is looked up when a scene is created on the device.
- * Limit: a frame whose buffers exceed the array (about 200 + 2 * lights * samples_per_light bytes per pixel of the
- * local image, rounded up to 8x8 tiles: 640x480 with 13 shadow rays per hit fits, 1920x1080 does not) is refused
- * with RTAMD_ERR_LIMIT.  When the screen bins of the primary rays do not fit beside the rest, those rays walk the
+ * Limit: a frame whose buffers exceed the array (per pixel of the local image, rounded up to 8x8 tiles, with
+ * n = lights * samples_per_light: 40 + n bytes without reflections, 104 + 2 n with one bounce, 184 + 2 n beyond:
+ * 640x480 with 13 shadow rays per hit fits at any depth, 1920x1080 does not) is refused with RTAMD_ERR_LIMIT.  When the screen bins of the primary rays do not fit beside the rest, those rays walk the
  * BVH instead (same image).
  * All calls on one GPU share that GPU's array, whatever the scene: frames enqueued through this entry point must
  * not overlap on a device (enqueue them on one stream, or order the streams); two that do race. */
