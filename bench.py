@@ -80,6 +80,9 @@ def parse():
                          "kernels at a time, one per hardware pipe, and eight or sixteen frames in flight are no faster in the steady "
                          "state and slower over a short batch, on one GPU and for one rank's share of a frame alike; fewer when the "
                          "frames' workspaces would take more than 64 GB)")
+    ap.add_argument("--workspace-limit-mb", type=int, default=-1,
+                    help="experiments: bound on one frame's work buffers, beyond which the library renders the frame in bands of rows "
+                         "(rtamd_scene_set_workspace_limit; 0 = no bound, default: the library's 2048)")
     ap.add_argument("--pipeline-depth", type=int, default=8,
                     help="several GPUs: frame buffers of the gather pipeline (at least the frames in flight); the gather of a frame may "
                          "lag that many frames behind its tracing")
@@ -264,6 +267,8 @@ def main():
     t0 = time.time()
     fly, params, cam = workloads.make_flyscene(w, max_leaf_faces=a.max_leaf, sah_bins=a.sah_bins, shadow_rays=a.shadow_rays, primary_rays=a.primary_rays, builder=a.builder)
     info = fly.info()
+    if a.workspace_limit_mb >= 0:
+        fly.set_workspace_limit(a.workspace_limit_mb << 20)
     init_s = time.time() - t0
     W, H = w["width"], w["height"]
 
