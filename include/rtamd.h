@@ -268,9 +268,13 @@ int rtamd_render_stats(rtamd_scene *scene, rtamd_stats *stats);
  * that much until the process ends -- so the call allocates, frees and creates nothing: no hipMalloc, no events,
  * no internal streams (everything is enqueued on hip_stream; RTAMD_FLAG_TIME_KERNELS is ignored).  The array's
  * address is looked up when a scene is created on the device.
- * Limit: a frame whose buffers exceed the array (per pixel of the local image, rounded up to 8x8 tiles, with
- * n = lights * samples_per_light: 40 + n bytes without reflections, 104 + 2 n with one bounce, 184 + 2 n beyond:
- * 640x480 with 13 shadow rays per hit fits at any depth, 1920x1080 does not) is refused with RTAMD_ERR_LIMIT.  When the screen bins of the primary rays do not fit beside the rest, those rays walk the
+ * Limit: the buffers take, per pixel of the local image rounded up to 8x8 tiles and with n = lights *
+ * samples_per_light, 40 + n bytes without reflections, 104 + 2 n with one bounce, 184 + 2 n beyond (640x480 with 13
+ * shadow rays per hit fits at any depth).  An unpartitioned frame (num_parts == 1) that does not fit is rendered in
+ * bands of rows, one after the other through the array (as under rtamd_scene_set_workspace_limit; 1920x1080 with one
+ * bounce goes in five bands); a frame that does not fit even in as many bands as its passes allow
+ * (bands * ssaa^2 * (max_reflections + 1) <= 64), or a partitioned one that does not fit, is refused with
+ * RTAMD_ERR_LIMIT.  When the screen bins of the primary rays do not fit beside the rest, those rays walk the
  * BVH instead (same image).
  * All calls on one GPU share that GPU's array, whatever the scene: frames enqueued through this entry point must
  * not overlap on a device (enqueue them on one stream, or order the streams); two that do race. */

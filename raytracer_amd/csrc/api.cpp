@@ -697,13 +697,13 @@ int band_height(int height, int bands) { return ((height + bands - 1) / bands + 
 // In how many bands of rows a frame is rendered: one, unless the frame is an unpartitioned image whose work buffers would
 // exceed the scene's limit; then as few as bring one band's buffers under it, while the stage counters last (every band
 // takes a frame's worth of them) and every band still has rows.
-int plan_bands(const rtamd_scene *s, const rtamd_render_params *p, const FrameShape &shape) {
-    if (s->workspace_limit == 0 || p->num_parts != 1) return 1;
+// (`limit` bytes for a workspace with `bins` screen bins and, if `keys`, the per-pixel keys of the face pass; 0 = no bound)
+int plan_bands(const rtamd_scene *s, const rtamd_render_params *p, const FrameShape &shape, size_t limit, size_t bins, bool keys) {
+    if (limit == 0 || p->num_parts != 1) return 1;
     Workspace sizes{};
     const size_t ntris = (size_t)s->info.num_device_faces;
-    const size_t bins = s->bin_primary ? (size_t)shape.bins_x * (size_t)shape.bins_y : 0;
-    const size_t whole = layout_workspace(nullptr, shape.slots, shape.nshadow, bins, ntris, s->face_primary, shape.depths, sizes);
-    if (whole <= s->workspace_limit) return 1;
+    const size_t whole = layout_workspace(nullptr, shape.slots, shape.nshadow, bins, ntris, keys, shape.depths, sizes);
+    if (whole <= limit) return 1;
     int bands = 1;
     const int most = std::min(kMaxStages / std::max(shape.stages, 1), (p->height + 7) / 8);
     while (bands < most) {
@@ -713,7 +713,7 @@ int plan_bands(const rtamd_scene *s, const rtamd_render_params *p, const FrameSh
             continue;
         }
         const size_t slots = (size_t)shape.tiles_x * (size_t)((rows + 7) / 8) * 64;
-        if (layout_workspace(nullptr, slots, shape.nshadow, bins, ntris, s->face_primary, shape.depths, sizes) <= s->workspace_limit) break;
+        if (layout_workspace(nullptr, slots, shape.nshadow, bins, ntris, keys, shape.depths, sizes) <= limit) break;
     }
     while (bands > 1 && (size_t)(bands - 1) * (size_t)band_height(p->height, bands) >= (size_t)p->height) --bands;
     return bands;
@@ -990,7 +990,7 @@ int rtamd_render_device(rtamd_scene *s, const rtamd_camera *cam, const rtamd_ren
     if (shape.pixels == 0) return RTAMD_OK;
     FrameSlot *slot = nullptr;
     if ((rc = acquire_slot(s, stream, &slot)) != RTAMD_OK) return rc;
-    const int bands = plan_bands(s, p, shape);
+    const int bands = plan_bands(s, p, shape, (size_t)s->workspace_limit, s->bin_primary ? (size_t)shape.bins_x * (size_t)shape.bins_y : 0, s->face_primary);
     if (bands == 1) {
         rc = ensure_workspace(s, *slot, shape.slots, (size_t)shape.bins_x * (size_t)shape.bins_y, shape.depths);
         if (rc != RTAMD_OK) return rc;
@@ -1028,26 +1028,45 @@ int rtamd_render_device_noalloc(rtamd_scene *s, const rtamd_camera *cam, const r
     if ((rc = frame_shape(s, p, shape)) != RTAMD_OK) return rc;
     s->have_frame = false;
     if (shape.pixels == 0) return RTAMD_OK;
-    // Work buffers: laid out in the device's static array instead of a hipMalloc'ed block.  Screen bins for the primary
-    // rays only when they fit as well (otherwise those rays walk the tree: same image).
+    // Work buffers: laid out in the device's static array instead of a hipMalloc'ed block.  A frame that does not fit whole
+    // is rendered in bands of rows (as rtamd_render_device does under its workspace limit), each band through the array.
     const size_t ntris = (size_t)s->info.num_device_faces;
-    const size_t bins = s->bin_primary ? (size_t)shape.bins_x * (size_t)shape.bins_y : 0;
     Workspace sizes{};
-    const size_t need_plain = layout_workspace(nullptr, shape.slots, shape.nshadow, 0, ntris, false, shape.depths, sizes);
+    const int bands = plan_bands(s, p, shape, kScratchBytes, 0, false);
+    rtamd_render_params pb = *p;
+    FrameShape first = shape; // the largest band (or the whole frame)
+    if (bands > 1) {
+        pb.row_tile = band_height(p->height, bands), pb.num_parts = bands, pb.part = 0;
+        if ((rc = frame_shape(s, &pb, first)) != RTAMD_OK) return rc;
+    }
+    const size_t need_plain = layout_workspace(nullptr, first.slots, first.nshadow, 0, ntris, false, first.depths, sizes);
     if (need_plain > kScratchBytes)
-        return fail(RTAMD_ERR_LIMIT, "a frame of %d x %d pixels with %zu shadow rays per hit needs %zu bytes of work buffers; "
-                    "rtamd_render_device_noalloc holds %zu (use rtamd_render_device)", p->width, shape.local_rows, shape.nshadow, need_plain, kScratchBytes);
+        return fail(RTAMD_ERR_LIMIT, "a frame of %d x %d pixels with %zu shadow rays per hit needs %zu bytes of work buffers%s; "
+                    "rtamd_render_device_noalloc holds %zu (use rtamd_render_device)", p->width, shape.local_rows, shape.nshadow, need_plain,
+                    bands > 1 ? " per band of rows, in as many bands as its passes allow" : "", kScratchBytes);
     // the buffers of the screen-space pass for the primary rays (per-pixel keys, or bins) only when they fit as well
-    const bool with_keys = s->face_primary && layout_workspace(nullptr, shape.slots, shape.nshadow, 0, ntris, true, shape.depths, sizes) <= kScratchBytes;
-    const bool with_bins = bins > 0 && layout_workspace(nullptr, shape.slots, shape.nshadow, bins, ntris, false, shape.depths, sizes) <= kScratchBytes;
+    // (otherwise those rays walk the tree: same image)
+    const size_t bins = s->bin_primary ? (size_t)first.bins_x * (size_t)first.bins_y : 0;
+    const bool with_keys = s->face_primary && layout_workspace(nullptr, first.slots, first.nshadow, 0, ntris, true, first.depths, sizes) <= kScratchBytes;
+    const bool with_bins = bins > 0 && layout_workspace(nullptr, first.slots, first.nshadow, bins, ntris, false, first.depths, sizes) <= kScratchBytes;
     char *base = s->scratch; // looked up when the scene was created
     if (!base && (rc = scratch_pointer(dev, &base)) != RTAMD_OK) return rc;
     FrameSlot &fs = s->static_slot;
-    layout_workspace(base, shape.slots, shape.nshadow, with_bins ? bins : 0, ntris, with_keys, shape.depths, fs.ws);
+    layout_workspace(base, first.slots, first.nshadow, with_bins ? bins : 0, ntris, with_keys, first.depths, fs.ws);
     fs.block = base;
     fs.bins = with_bins ? bins : 0;
     fs.stream = (hipStream_t)hip_stream;
-    return enqueue_frame(s, fs, shape, cam, p, rgb, face_id, t_hit, (hipStream_t)hip_stream, /*plain=*/true);
+    if (bands == 1) return enqueue_frame(s, fs, shape, cam, p, rgb, face_id, t_hit, (hipStream_t)hip_stream, /*plain=*/true);
+    for (int b = 0; b < bands; ++b) {
+        pb.part = b;
+        FrameShape band_shape;
+        if ((rc = frame_shape(s, &pb, band_shape)) != RTAMD_OK) return rc;
+        const size_t at = (size_t)b * (size_t)pb.row_tile * (size_t)p->width; // first pixel of the band
+        rc = enqueue_frame(s, fs, band_shape, cam, &pb, rgb + 3 * at, face_id ? face_id + at : nullptr, t_hit ? t_hit + at : nullptr,
+                           (hipStream_t)hip_stream, /*plain=*/true, b, bands, p);
+        if (rc != RTAMD_OK) return rc;
+    }
+    return RTAMD_OK;
 }
 
 

@@ -1,6 +1,7 @@
 """rtamd_render_device_noalloc (work buffers in the library's static device array, nothing allocated) against
 rtamd_render_device on the same inputs, through the C ABI: every output plane bit for bit, on two calls in a row, the
 second with a smaller image, so that whatever the first call left in the shared array must not leak into the second.
+A frame too large for the array goes through it in bands of rows; one too large even so is refused.
 Collected last on purpose (the array is shared by every scene on the GPU)."""
 import numpy as np
 import pytest
@@ -49,10 +50,22 @@ def test_noalloc_entry_point_matches_render_device_twice_in_a_row(name):
     same(planes(fly, 136, 100, noalloc=True, **part), planes(fly, 136, 100, noalloc=False, **part))
 
 
+def test_noalloc_entry_point_renders_a_frame_larger_than_its_array_in_bands():
+    """A 1080p frame needs more work buffers than the static array holds; the entry point cuts it into bands of rows that
+    fit, one after the other through the array, and the frame is the same bit for bit."""
+    fly = R.Flyscene(model=scene_path("reflect_test"), output="").initialize(64, 64)
+    big = planes(fly, 1920, 1080, noalloc=True, max_reflections=1)
+    same(big, planes(fly, 1920, 1080, noalloc=False, max_reflections=1))
+    assert big[3][2] > 0
+    same(planes(fly, 200, 120, noalloc=True), planes(fly, 200, 120, noalloc=False))  # and a small one right behind it
+
+
 def test_noalloc_entry_point_refuses_frames_beyond_its_array():
-    fly = R.Flyscene(model=scene_path("toy"), output="").initialize(64, 64)
+    """Every band takes a frame's worth of stage counters, so a frame of many passes can be cut into few bands only: 24 passes
+    (2 x 2 samples, five bounces) leave two bands, and half a 1080p frame does not fit the array."""
+    fly = R.Flyscene(model=scene_path("reflect_test"), output="").initialize(64, 64)
     with pytest.raises(L.RtamdError) as e:
-        planes(fly, 1920, 1080, noalloc=True)
+        planes(fly, 1920, 1080, noalloc=True, ssaa_level=2, max_reflections=5)
     assert e.value.code == L.ERR_LIMIT and "rtamd_render_device_noalloc holds" in str(e.value)
     # the scene is still usable afterwards
     same(planes(fly, 64, 64, noalloc=True), planes(fly, 64, 64, noalloc=False))

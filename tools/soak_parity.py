@@ -1,12 +1,14 @@
-"""Soak: random triangle soups (the generator of tests/test_gpu_parity.py) and dust clouds, the default path (screen
-bins, shadow grids) and the device builders against the tree walk for every ray, bit for bit, at sizes and seeds the
-test suite does not run:  python tools/soak_parity.py [FIRST_SEED [COUNT]]"""
+"""Soak: random triangle soups (the generator of tests/test_gpu_parity.py) and dust clouds, the default path (primary rays
+face by face in screen space, shadow grids), the screen bins and the device builders against the tree walk for every ray,
+bit for bit, whole and in as many bands of rows as the library will cut (each band a partitioned frame), at sizes and
+seeds the test suite does not run:  python tools/soak_parity.py [FIRST_SEED [COUNT]]"""
 import sys
 
 import numpy as np
 
-sys.path.insert(0, ".")
-sys.path.insert(0, "tests")
+_ROOT = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+sys.path.insert(0, _ROOT)
+sys.path.insert(0, _ROOT + "/tests")
 import raytracer_amd as R  # noqa: E402
 from raytracer_amd import _lib as L  # noqa: E402
 from test_gpu_parity import _random_soup  # noqa: E402
@@ -28,15 +30,22 @@ for seed in range(first, first + count):
     ref = R.Flyscene(primary_rays=L.PRIMARY_RAYS_TREE, shadow_rays=L.SHADOW_RAYS_TREE, **kw).initialize(W, H)
     ref.set_params(max_reflections=2)
     want = ref.render()
-    for build in (dict(primary_rays=L.PRIMARY_RAYS_BINS), dict(primary_rays=L.PRIMARY_RAYS_BINS, builder=L.BUILDER_DEVICE_LBVH)):
-        f = R.Flyscene(**kw, **build).initialize(W, H)
-        f.set_params(max_reflections=2)
-        got = f.render()
-        same = np.array_equal(got["face_id"], want["face_id"]) and np.array_equal(got["rgb"].view(np.uint32), want["rgb"].view(np.uint32))
-        if not same:
-            bad += 1
-            print("MISMATCH seed %d %dx%d %s: %d face ids, %d colour words differ" % (
-                seed, W, H, build, int((got["face_id"] != want["face_id"]).sum()), int((got["rgb"].view(np.uint32) != want["rgb"].view(np.uint32)).sum())), flush=True)
+    for build in (dict(), dict(builder=L.BUILDER_DEVICE_LBVH), dict(primary_rays=L.PRIMARY_RAYS_BINS),
+                  dict(primary_rays=L.PRIMARY_RAYS_BINS, builder=L.BUILDER_DEVICE_LBVH)):
+        for banded in (False, True):
+            f = R.Flyscene(**kw, **build).initialize(W, H)
+            f.set_params(max_reflections=2)
+            if banded:
+                f.set_workspace_limit(1)  # as many bands as the stage counters allow
+            got = f.render()
+            same = np.array_equal(got["face_id"], want["face_id"]) and np.array_equal(got["rgb"].view(np.uint32), want["rgb"].view(np.uint32))
+            same = same and got["stats"].rays_shadow == want["stats"].rays_shadow and got["stats"].rays_bounce == want["stats"].rays_bounce
+            if not same:
+                bad += 1
+                print("MISMATCH seed %d %dx%d %s banded=%s: %d face ids, %d colour words differ" % (
+                    seed, W, H, build, banded, int((got["face_id"] != want["face_id"]).sum()),
+                    int((got["rgb"].view(np.uint32) != want["rgb"].view(np.uint32)).sum())), flush=True)
+            f.close()
     if (seed - first) % 8 == 7:
         print("seeds %d..%d done, %d mismatches so far" % (first, seed, bad), flush=True)
 print("soak: %d seeds, %d mismatches" % (count, bad))
