@@ -166,7 +166,8 @@ size_t layout_workspace(char *base, size_t slots, size_t nshadow, size_t bins, s
     ws.stage = (StageCounters *)(uintptr_t)base;
     ws.work = (WorkCounters *)((uintptr_t)base + 2048);
     ws.bin_state = nullptr, ws.bin_count = nullptr, ws.bin_start = nullptr, ws.bin_entries = nullptr, ws.big = nullptr;
-    ws.pix_key = nullptr;
+    ws.pix_key = nullptr, ws.tile_flag = nullptr;
+    ws.prefilled = 0;
     ws.bin_capacity = 0;
     if (bins || keys) { // right behind the counters: one sweep clears all of them at the start of a frame
         ws.bin_state = (BinState *)take(256);
@@ -203,6 +204,7 @@ size_t layout_workspace(char *base, size_t slots, size_t nshadow, size_t bins, s
     if (keys) {
         align(256);
         ws.pix_key = (unsigned long long *)take(cap * 8);
+        ws.tile_flag = (int32_t *)take(cap / 64 * 4); // right behind the keys: cleared together with them
     }
     if (bins || keys) {
         align(256);
@@ -233,7 +235,7 @@ int ensure_workspace(rtamd_scene *s, FrameSlot &fs, size_t slots, size_t bins_ne
     const size_t total = layout_workspace(nullptr, slots, nshadow, bins, ntris, s->face_primary, depths, sizes);
     HIP_TRY(hipMalloc(&fs.block, total));
     layout_workspace((char *)fs.block, slots, nshadow, bins, ntris, s->face_primary, depths, fs.ws);
-    if (fs.ws.pix_key) HIP_TRY(hipMemset(fs.ws.pix_key, 0, (size_t)fs.ws.capacity * sizeof(unsigned long long)));
+    if (fs.ws.pix_key) HIP_TRY(hipMemset(fs.ws.pix_key, 0, (size_t)fs.ws.capacity * sizeof(unsigned long long) + (size_t)fs.ws.capacity / 64 * 4));
     fs.ws.bin_feedback = feedback;
     fs.ws.stage_feedback = stage_feedback;
     fs.bins = bins;
@@ -805,6 +807,13 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
             fs.frames_without_bins = 0;
         }
     }
+    // Does the view leave most pixels untouched?  Then the output planes are filled with the miss values in one sweep and
+    // the compaction looks at the touched tiles only (prep_kernel); where most pixels are hit, or faces too large for the
+    // face pass must be tested pixel by pixel anyway, that sweep is wasted (1.1 M-face field at 4K: 10 % of the frame).
+    // Without a report from an earlier frame of the view the sparse form is assumed.
+    bool sparse_view = true;
+    if (fs.feedback && fs.view_key == view_key && fs.feedback[3] != 0 && fs.feedback[1] > 0) sparse_view = false;
+    if (expect_hits[(size_t)stage_base] >= 0 && 2 * (size_t)expect_hits[(size_t)stage_base] >= pixels) sparse_view = false;
     if (bins_ok || faces_ok) {
         const float *m = cam->inv_view;
         const double a = m[0], b = m[1], c = m[2], d0 = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
@@ -886,17 +895,21 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
     // The per-pixel keys (indexed by local row and column) are zero between passes: the compaction kernel reads each once
     // and puts the zero back, and a fresh workspace is cleared when it is allocated.  Only the array shared by all callers
     // of the allocation-free entry point may hold anything.
-    const size_t key_clear = faces_ok && plain ? pixels * sizeof(unsigned long long) : 0;
+    const size_t key_clear = faces_ok && plain ? (size_t)fs.ws.capacity * sizeof(unsigned long long) + (size_t)fs.ws.capacity / 64 * 4 : 0;
     int stage = stage_base;
     for (int xs = 0; xs < S; ++xs)
         for (int ys = 0; ys < S; ++ys) {
             fc.sub_x = (float)xs / S; // src/flyscene.cpp:816-817
             fc.sub_y = (float)ys / S;
             fc.accumulate = (xs | ys) != 0;
+            // With the face pass planned, the pass's first launch also writes what a primary miss leaves into every pixel of
+            // the output planes (whole lines, once), and the compaction kernel skips the tiles no face was accepted in;
+            // a pass that ADDS to the planes (SSAA passes after the first) keeps the pixel-by-pixel form.
+            ws_frame.prefilled = faces_ok && !fc.accumulate && sparse_view;
             if (stage == 0) // (the first pass of the first band)
-                launch_prep(fc, ws_frame, fs.block, 4096 + bin_clear, ws_frame.pix_key, key_clear, stream);
+                launch_prep(fc, ws_frame, fs.block, 4096 + bin_clear, ws_frame.pix_key, key_clear, rgb, face_id, t_hit, stream);
             else
-                launch_prep(fc, ws_frame, (char *)fs.block + 4096, bin_clear, ws_frame.pix_key, key_clear, stream);
+                launch_prep(fc, ws_frame, (char *)fs.block + 4096, bin_clear, ws_frame.pix_key, key_clear, rgb, face_id, t_hit, stream);
             // Fused form: the shadow rays of level d share a launch with the closest hits of level d + 1, and the shading of
             // level d with the compaction of level d + 1 (each pair needs only what the launch before it produced), all on
             // the caller's stream.  The GPU runs only a few kernels at a time however many streams feed it, so what a frame

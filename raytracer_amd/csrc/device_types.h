@@ -116,6 +116,8 @@ struct Workspace {
     // Primary rays resolved face by face (face_raster_kernel): per pixel of the local image, the complement of (distance
     // bits, inverted rank) of the best face so far, zero = none; nullptr: not in use for this frame
     unsigned long long *pix_key;
+    int32_t *tile_flag;       // face pass: per 8x8 tile of the local image, set when a face was accepted for one of its pixels
+    int32_t prefilled;        // the output planes already hold what a primary miss leaves (prep_kernel): misses write nothing
     // screen binning of the primary rays; bin_entries == nullptr: not in use
     BinState *bin_state;
     int32_t *bin_count;   // per bin: faces whose projection touches it; then the fill cursor

@@ -11,7 +11,8 @@ namespace rtamd {
 
 // `depth` = recursion depth of the stage: selects the ray queue (depth % 3) and the hit list (depth & 1).
 // Start of a pass: zeroes `zero_bytes` (a multiple of 16, 16-byte aligned) of counters and fills the pass's screen-coordinate tables.
-void launch_prep(const FrameConst &fc, const Workspace &ws, void *zero, size_t zero_bytes, void *zero_b, size_t zero_b_bytes, hipStream_t stream);
+void launch_prep(const FrameConst &fc, const Workspace &ws, void *zero, size_t zero_bytes, void *zero_b, size_t zero_b_bytes, float *rgb,
+                 int32_t *face_id, float *t_hit, hipStream_t stream);
 // Primary rays of one pass resolved face by face into ws.pix_key (zeroed by launch_prep); launch_compact reads it.
 void launch_primary_faces(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, hipStream_t stream);
 // Screen binning of the primary rays of one pass (ws.bin_entries must be set): count, claim, fill, test.

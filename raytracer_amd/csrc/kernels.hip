@@ -1271,6 +1271,7 @@ __device__ __forceinline__ void raster_pair(const FrameConst &fc, const Workspac
     if (dot(cross(v2 - v1, hp - v1), n) < 0) return;
     if (dot(cross(v0 - v2, hp - v2), n) < 0) return;
     atomicMax(cell, ~hit_key(t, __float_as_int(r1.w)));
+    if (ws.prefilled) ws.tile_flag[(lr >> 3) * fc.tiles_x + (x >> 3)] = 1; // the compaction kernel then looks at flagged tiles only
 }
 
 template <bool COUNT>
@@ -1592,7 +1593,7 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool from_keys = PRIMARY && ws.pix_key != nullptr && keys_accepted(ws); // the pass was resolved face by face
     if (PRIMARY && ws.pix_key != nullptr && block == 0 && tid == 0 && ws.bin_feedback) { // the pass's verdict, for the next frames of the view
-        ws.bin_feedback[0] = 0, ws.bin_feedback[1] = 0;
+        ws.bin_feedback[0] = 0, ws.bin_feedback[1] = ws.bin_state->num_big; // [1]: faces too large for the face pass
         ws.bin_feedback[2] = from_keys ? 0 : 1, ws.bin_feedback[3] = 1;
     }
     // the grid may be smaller than the work (it is sized from what earlier frames of the view needed): stride over it
@@ -1614,7 +1615,15 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
             // What face_raster_kernel left in the pixel: complement of (distance bits, inverted rank); zero = no face.
             // Then the faces too large for that kernel and the spheres, against this pixel's ray, under the same
             // rule: nearest wins, equal distances go to the later face, a sphere loses a tie (intersects(), :673-676).
-            if (valid) {
+            // A tile no face was accepted in holds no key (face_raster_kernel flags the tiles it touches); with the planes
+            // prefilled and neither listed faces nor spheres to test, its pixels are done.
+            int flagged = 1;
+            if (ws.prefilled) { // (only such a pass sets flags)
+                flagged = slot < total ? ws.tile_flag[slot >> 6] : 0;
+                if (flagged && lane == 0) ws.tile_flag[slot >> 6] = 0; // read once per pass, left clean for the next one
+                if (ws.bin_state->num_big != 0 || sc.num_spheres != 0) flagged = 1;
+            }
+            if (valid && flagged) {
                 float tbest = FLT_MAX;
                 int best_rank = -1;
                 unsigned long long *const cell = ws.pix_key + (row * fc.width + x); // (a frame's pixels fit 31 bits: frame_shape)
@@ -1656,8 +1665,9 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
         } else {
             tri = valid ? ws.slot_tri[slot] : -2;
             t_found = valid && tri != -2 ? ws.slot_t[slot] : 0.0f;
-            // the face raster ran but gave way to the tree walk: its keys are dropped here
+            // the face raster ran but gave way to the tree walk: its keys and tile flags are dropped here
             if (PRIMARY && ws.pix_key != nullptr && valid) ws.pix_key[(size_t)row * (size_t)fc.width + (size_t)x] = 0ull;
+            if (PRIMARY && ws.pix_key != nullptr && ws.prefilled && slot < total && lane == 0) ws.tile_flag[slot >> 6] = 0;
         }
         t_of[j] = t_found;
         const bool hit = tri != -2;
@@ -1713,7 +1723,8 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
             int x = 0, row = 0;
             const bool valid = slot_pixel_of_wave(fc, slot, x, row) && slot < total;
             pix = row * fc.width + x;
-            if (valid) {
+            const bool filled = from_keys && ws.prefilled; // prep_kernel wrote what a miss leaves
+            if (valid && (hit || !filled)) {
                 if (face_id) face_id[pix] = tri >= 0 ? __float_as_int(sc.tris[tri * 4 + 1].w) : tri;
                 if (t_hit) t_hit[pix] = t;
                 if (!hit) { // background of a primary ray, :653-658
@@ -1919,8 +1930,23 @@ __global__ __launch_bounds__(256) void shade_compact_kernel(DeviceScene sc, Fram
 
 // Start of a pass: zero the counters the pass counts up from (`zero16` 16-byte words from `zero`), and fill the
 // tables of the pass's screen coordinates (primary_direction): dir_x per image column, dir_y per LOCAL row.
-__global__ __launch_bounds__(256) void prep_kernel(FrameConst fc, Workspace ws, int4 *zero, int zero16, int4 *zero_b, int zero_b16) {
+// With ws.prefilled it also writes what a primary ray that hits nothing leaves in the output planes (background colour,
+// RTAMD_FACE_MISS, distance 0: src/flyscene.cpp:650-658) into EVERY pixel, in whole coalesced lines; the compaction
+// kernel then skips the tiles no face was accepted in, and the shading overwrites the pixels that were hit.
+__global__ __launch_bounds__(256) void prep_kernel(FrameConst fc, Workspace ws, int4 *zero, int zero16, int4 *zero_b, int zero_b16, float *rgb,
+                                                   int32_t *face_id, float *t_hit) {
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (ws.prefilled) {
+        const int pixels = fc.local_rows * fc.width, stride = (int)gridDim.x * 256;
+        for (int k = i; k < 3 * pixels; k += stride) {
+            const int c = k - (k / 3) * 3;
+            rgb[k] = c == 0 ? fc.bg[0] : c == 1 ? fc.bg[1] : fc.bg[2];
+        }
+        if (face_id)
+            for (int k = i; k < pixels; k += stride) face_id[k] = -2;
+        if (t_hit)
+            for (int k = i; k < pixels; k += stride) t_hit[k] = 0.0f;
+    }
     for (int k = i; k < zero16; k += (int)gridDim.x * 256) zero[k] = make_int4(0, 0, 0, 0);
     for (int k = i; k < zero_b16; k += (int)gridDim.x * 256) zero_b[k] = make_int4(0, 0, 0, 0);
     const int nx = fc.tiles_x * 8, ny = fc.tiles_y * 8;
@@ -2004,11 +2030,13 @@ int walk_grid(long long groups) {
 
 float raster_margin_floor() { return kBinMarginFloor; }
 
-void launch_prep(const FrameConst &fc, const Workspace &ws, void *zero, size_t zero_bytes, void *zero_b, size_t zero_b_bytes, hipStream_t stream) {
+void launch_prep(const FrameConst &fc, const Workspace &ws, void *zero, size_t zero_bytes, void *zero_b, size_t zero_b_bytes, float *rgb,
+                 int32_t *face_id, float *t_hit, hipStream_t stream) {
     const int zero16 = (int)((zero_bytes + 15) / 16), zero_b16 = (int)((zero_b_bytes + 15) / 16);
-    const int items = std::max(std::max(zero16, zero_b16), (fc.tiles_x + fc.tiles_y) * 8);
-    const int blocks = std::max(1, std::min(2048, (items + 255) / 256));
-    prep_kernel<<<blocks, 256, 0, stream>>>(fc, ws, (int4 *)zero, zero16, (int4 *)zero_b, zero_b16);
+    int items = std::max(std::max(zero16, zero_b16), (fc.tiles_x + fc.tiles_y) * 8);
+    if (ws.prefilled) items = std::max(items, (int)std::min<long long>(3ll * fc.local_rows * fc.width / 4, 1 << 30)); // four stores per thread
+    const int blocks = std::max(1, std::min(ws.prefilled ? 16384 : 2048, (items + 255) / 256));
+    prep_kernel<<<blocks, 256, 0, stream>>>(fc, ws, (int4 *)zero, zero16, (int4 *)zero_b, zero_b16, rgb, face_id, t_hit);
 }
 
 // Primary rays of one pass face by face (ws.pix_key must be set and zeroed): one launch.  The pixels are resolved by
