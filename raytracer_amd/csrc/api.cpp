@@ -829,6 +829,11 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
             for (int k = 0; k < 9; ++k) fc.lin_inv[k] = (float)inv[k];
             for (int k = 0; k < 3; ++k) fc.cam_e[k] = (float)(inv[3 * k] * dt[0] + inv[3 * k + 1] * dt[1] + inv[3 * k + 2] * dt[2]);
             if (!(std::fabs(fc.cam_e[2] - 1.0f) > 1e-6f)) bins_ok = faces_ok = false;
+            // the divisions of the projection, done once here: project_point multiplies
+            fc.proj_s = (float)(1.0 / ((double)fc.cam_e[2] - 1.0));
+            fc.px_off = (float)((double)fc.vp[0] + 0.5 * (double)fc.vp[2]), fc.px_scale = (float)(0.5 * (double)fc.vp[2] / (double)fc.ax);
+            fc.py_off = (float)((double)fc.vp[1] + 0.5 * (double)fc.vp[3]), fc.py_scale = (float)(0.5 * (double)fc.vp[3] / (double)fc.scale);
+            if (!std::isfinite(fc.proj_s) || !std::isfinite(fc.px_scale) || !std::isfinite(fc.py_scale)) bins_ok = faces_ok = false;
         }
         fc.bins_x = bins_x, fc.bins_y = bins_y;
         // four times the worst-case error of a projected on-screen corner (derivation: RT_BIN_MARGIN in kernels.hip), with the
@@ -836,7 +841,7 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
         const double unit = 5.9604644775390625e-8; // 2^-24
         const double px_per_n = std::max(0.5 * (double)p->height / std::max(1e-6, (double)std::fabs(fc.scale)),
                                          0.5 * (double)p->width / std::max(1e-6, (double)std::fabs(fc.ax)));
-        const double bound = px_per_n * 26.0 * unit + 4.0 * unit * (double)p->width;
+        const double bound = px_per_n * 32.0 * unit + 6.0 * unit * (double)p->width;
         fc.raster_margin = std::max(raster_margin_floor(), (float)(4.0 * bound));
     }
     fs.ws.dir_y = fs.ws.dir_x + tiles_x * 8;

@@ -54,6 +54,8 @@ struct FrameConst {
     // inverse applied to (inv_view translation - origin); bins of kBinPixels^2 pixels over the whole image
     float lin_inv[9];
     float cam_e[3];
+    float proj_s;                               // 1 / (cam_e[2] - 1)
+    float px_off, px_scale, py_off, py_scale;   // pixel = (px_off + n.x * px_scale, py_off - n.y * py_scale) for a direction n of the camera
     int32_t bins_x, bins_y;
     float raster_margin; // widening of projected boxes and triangles in pixels (error bound: RT_BIN_MARGIN in kernels.hip)
 };

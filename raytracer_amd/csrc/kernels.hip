@@ -874,19 +874,24 @@ struct PixelBox {
 // max(kBinMarginFloor, four times the bound below)).
 //
 // Bound on the error of a projected corner, u = 2^-24 the unit roundoff.  project_point forms r = p - o, q = M r with M the
-// float rounding of the inverse camera matrix, s = q.z / (e.z - 1), n = q.xy / s - e.xy and the pixel from n:
+// float rounding of the inverse camera matrix, s = q.z * (1 / (e.z - 1)), n = q.xy * rcp(s) - e.xy and the pixel as an
+// offset plus n times a scale; the reciprocals and scales are rounded once on the host (u each), the hardware reciprocal is
+// good to one unit in the last place (2 u), every product and sum adds u.  (Only the candidates depend on these figures;
+// whether a pixel is hit is decided by the reference's own arithmetic in the exact test.)
 //   each component of q is off by at most 4 u R, R = |q.x| + |q.y| + |q.z| (three products, two sums, the rounding of M);
-//   s inherits that plus its own division: 4 u R + u s;
-//   n.x = q.x / s - e.x is then off by at most (8 R / s + 2) u (1 + |n.x|) / 2 <= (8 R / s + 2) u for a corner on the screen,
+//   s inherits that plus two roundings: 4 u R + 2 u s;
+//   n.x = q.x rcp(s) - e.x is then off by at most (8 R / s + 6) u (1 + |n.x|) / 2 <= (8 R / s + 6) u for a corner on the screen,
 //   where |n.x|, |n.y| <= 1 (tangent of half the field of view times the aspect) and so R <= 3 s;
-//   the pixel is n scaled by (W / 2) / (aspect tan(fovy / 2)) = (H / 2) / tan(fovy / 2) = 0.87 H at the reference's 60 degrees.
-// So a corner ON the screen lands within 0.87 H * 26 u + 4 u W of its true pixel position: 1.4e-6 H + 2.4e-7 W, i.e.
-// 0.0015 pixel at 1080p and 0.0077 pixel at 8K.  A corner far OFF the screen may be off by much more in the coordinate that
+//   the pixel is n scaled by (W / 2) / (aspect tan(fovy / 2)) = (H / 2) / tan(fovy / 2) = 0.87 H at the reference's 60 degrees,
+//   with three more roundings of a number of at most W.
+// So a corner ON the screen lands within 0.87 H * 30 u + 3 u W of its true pixel position; the host takes
+// 0.87 H * 32 u + 6 u W: 1.7e-6 H + 3.6e-7 W, i.e. 0.0025 pixel at 1080p and 0.010 pixel at 8K.  A corner far OFF the screen
+// may be off by much more in the coordinate that
 // is on the screen (R / s is large), but only the box's extremes use it, and a wrong extreme at a corner changes which
 // pixels are tested only next to that corner, which is off the screen.  Corners with s <= 1e-6 R count as unprojectable
 // and send the face to the per-pixel list; the edge functions are only used with every corner within 16384 pixels
 // (R / s <= 20 at 1080p: 0.009 pixel).  The exact test's own rounding moves a face's boundary by a few u of the face's
-// size in pixels (0.001 pixel for a face 10^4 pixels wide).  The floor of a sixteenth of a pixel is eight times the 8K bound;
+// size in pixels (0.001 pixel for a face 10^4 pixels wide).  The floor of a sixteenth of a pixel is six times the 8K bound;
 // beyond that the host scales the margin with the image.
 // It matters that the margin is not larger than needed for faces smaller than a pixel (a distant mesh): their box holds a
 // pixel centre with probability (size + 2 margin)^2, and a quarter of a pixel made the work 3-4 times what it had to be.
@@ -904,13 +909,14 @@ __device__ __forceinline__ bool project_point(const FrameConst &fc, V3 p, float 
     const float qy = m[3] * r.x + (m[4] * r.y + m[5] * r.z);
     const float qz = m[6] * r.x + (m[7] * r.y + m[8] * r.z);
     // r = s * L * (n + e) with n.z = -1  ->  q = s * (n + e)
-    const float s = qz / (fc.cam_e[2] - 1.0f);
+    const float s = qz * fc.proj_s;
     const float reach = fabsf(qx) + fabsf(qy) + fabsf(qz);
     behind = s < -1e-4f * reach;
     if (!(s > 1e-6f * reach)) return false;
-    const float nx = qx / s - fc.cam_e[0], ny = qy / s - fc.cam_e[1];
-    px = fc.vp[0] + (nx / fc.ax + 1.0f) * (0.5f * fc.vp[2]);
-    py = fc.vp[1] + (1.0f - ny / fc.scale) * (0.5f * fc.vp[3]);
+    const float rs = __builtin_amdgcn_rcpf(s); // (no division on this path needs to be correctly rounded: see the bound above)
+    const float nx = qx * rs - fc.cam_e[0], ny = qy * rs - fc.cam_e[1];
+    px = fc.px_off + nx * fc.px_scale;
+    py = fc.py_off - ny * fc.py_scale;
     return px == px && py == py;
 }
 
@@ -1211,14 +1217,15 @@ __device__ __forceinline__ bool cluster_outside_part(const DeviceScene &sc, cons
     const float qx = m[0] * r.x + (m[1] * r.y + m[2] * r.z);
     const float qy = m[3] * r.x + (m[4] * r.y + m[5] * r.z);
     const float qz = m[6] * r.x + (m[7] * r.y + m[8] * r.z);
-    const float s = qz / (fc.cam_e[2] - 1.0f); // as in project_point
+    const float s = qz * fc.proj_s; // as in project_point
     const float reach = fabsf(qx) + fabsf(qy) + fabsf(qz);
     float smin = s, rmax = reach;
     for (int off = 1; off < 8; off <<= 1) smin = fminf(smin, __shfl_xor(smin, off, 64)), rmax = fmaxf(rmax, __shfl_xor(rmax, off, 64));
     if (!(smin > 0.02f * rmax)) return false; // a corner near or behind the eye plane (or not a number): no verdict
-    const float nx = qx / s - fc.cam_e[0], ny = qy / s - fc.cam_e[1];
-    const float px = fc.vp[0] + (nx / fc.ax + 1.0f) * (0.5f * fc.vp[2]);
-    const float py = fc.vp[1] + (1.0f - ny / fc.scale) * (0.5f * fc.vp[3]);
+    const float rs = __builtin_amdgcn_rcpf(s);
+    const float nx = qx * rs - fc.cam_e[0], ny = qy * rs - fc.cam_e[1];
+    const float px = fc.px_off + nx * fc.px_scale;
+    const float py = fc.py_off - ny * fc.py_scale;
     float xlo = px, xhi = px, ylo = py, yhi = py;
     for (int off = 1; off < 8; off <<= 1) {
         xlo = fminf(xlo, __shfl_xor(xlo, off, 64)), xhi = fmaxf(xhi, __shfl_xor(xhi, off, 64));
