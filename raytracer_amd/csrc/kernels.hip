@@ -1605,6 +1605,17 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
     }
     // the grid may be smaller than the work (it is sized from what earlier frames of the view needed): stride over it
     for (int first = block * (256 * kCompactSegments); first < total; first += nblocks * (256 * kCompactSegments)) {
+    // A run of tiles none of which the face pass flagged holds no hit, and its pixels already hold the miss values: the
+    // workgroup moves on (the same decision in every thread; no LDS was touched, so the barrier below is not needed).
+    if (PRIMARY && from_keys && ws.prefilled && ws.bin_state->num_big == 0 && sc.num_spheres == 0) {
+        int any = 0;
+#pragma unroll
+        for (int j = 0; j < kCompactSegments; ++j) {
+            const int slot = first + j * 256 + tid;
+            if (slot < total) any |= ws.tile_flag[slot >> 6];
+        }
+        if (!__syncthreads_or(any)) continue;
+    }
 
     // ---- pass 1: classify the slots of every segment, count per wave
     int tri_of[kCompactSegments];
@@ -1945,7 +1956,20 @@ __global__ __launch_bounds__(256) void prep_kernel(FrameConst fc, Workspace ws, 
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
     if (ws.prefilled) {
         const int pixels = fc.local_rows * fc.width, stride = (int)gridDim.x * 256;
-        for (int k = i; k < 3 * pixels; k += stride) {
+        // four floats a store where the plane allows it: float 4 k + e holds channel (k + e) mod 3
+        // (selected component by component: a choice between whole float4 values is lowered to an array in scratch memory)
+        const int quads = ((uintptr_t)rgb & 15) == 0 ? (3 * pixels) >> 2 : 0;
+        const float b0 = fc.bg[0], b1 = fc.bg[1], b2 = fc.bg[2];
+        for (int k = i; k < quads; k += stride) {
+            const int m = k - (k / 3) * 3;
+            float4 v;
+            v.x = m == 0 ? b0 : m == 1 ? b1 : b2;
+            v.y = m == 0 ? b1 : m == 1 ? b2 : b0;
+            v.z = m == 0 ? b2 : m == 1 ? b0 : b1;
+            v.w = v.x;
+            ((float4 *)rgb)[k] = v;
+        }
+        for (int k = 4 * quads + i; k < 3 * pixels; k += stride) {
             const int c = k - (k / 3) * 3;
             rgb[k] = c == 0 ? fc.bg[0] : c == 1 ? fc.bg[1] : fc.bg[2];
         }
