@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-end evidence for profiles/: run on the GPU box from the repository root.
+# Evidence for profiles/ (bench lines, kernel traces, counters): run on the GPU box from the repository root.
 #   tools/collect_profiles.sh TAG      -> gpurun_out/profiles_TAG/
 # Order: counters and the kernels-alone trace first, copied to profiles/ on the box, so that the bench lines taken
 # afterwards quote the counters of the very build they measure (bench.py reads them from profiles/).
