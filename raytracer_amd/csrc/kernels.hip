@@ -1282,21 +1282,26 @@ __device__ __forceinline__ void raster_pair(const FrameConst &fc, const Workspac
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(256) void face_raster_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int num_tris) {
+// `fshift`: a wave takes 1 << fshift faces (6: one per lane).  A mesh of few faces makes few waves -- 69 K faces are 1085
+// waves of 64, a seventh of what the chip holds, each with hundreds of pairs to step through one batch after the other -- so
+// the launcher gives a wave fewer faces then (launch_primary_faces); their pairs are dealt over all 64 lanes either way.
+__global__ __launch_bounds__(256) void face_raster_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int num_tris, int fshift) {
     __shared__ float4 s_rec[4][4][64]; // per wave: the four quarters of its faces' records
     __shared__ int4 s_box[4][64];      // ... first pixel column and row, box width, floor(2^32 / width)
     __shared__ int s_off[4][64];       // ... number of the face's first pair
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const int tri = (int)(blockIdx.x * 256 + threadIdx.x);
+    const int wave_first = ((int)blockIdx.x * 4 + wave) << fshift;
+    const int tri = wave_first + lane;
+    const bool holds = lane < (1 << fshift) && tri < num_tris; // this lane holds a face
     unsigned w_box = 0, w_plane = 0, w_edge = 0;
     ProjectedFace f;
     f.empty = true, f.unbounded = false, f.px0 = f.py0 = 0, f.px1 = f.py1 = -1;
     // a rank that renders some rows only: groups of faces that lie in other ranks' rows are dropped unseen
+    // (a wave's faces lie in one group of 64 records: 1 << fshift divides 64)
     bool skip = false;
-    if (RT_CLUSTER_CULL(fc) && (int)(blockIdx.x * 256) + wave * 64 < num_tris)
-        skip = cluster_outside_part(sc, fc, (int)(blockIdx.x * 4) + wave, lane);
-    if (tri < num_tris && !skip) f = project_face(sc, fc, tri);
-    if (COUNT && tri < num_tris && !skip) ++w_box; // faces projected
+    if (RT_CLUSTER_CULL(fc) && wave_first < num_tris) skip = cluster_outside_part(sc, fc, wave_first >> 6, lane);
+    if (holds && !skip) f = project_face(sc, fc, tri);
+    if (COUNT && holds && !skip) ++w_box; // faces projected
     int w = f.px1 - f.px0 + 1, h = f.py1 - f.py0 + 1;
     const bool large = f.unbounded || w * h > kHugePixels;
     // From here on the box's rows are this part's own (packed) rows: a face that spans the row tiles of several parts is
@@ -1316,9 +1321,10 @@ __global__ __launch_bounds__(256) void face_raster_kernel(DeviceScene sc, FrameC
     int most = count;
     for (int off = 32; off > 0; off >>= 1) most = max(most, __shfl_xor(most, off, 64));
     if (most > 0) {
-        const float4 pn = sc.tris[(size_t)min(tri, num_tris - 1) * 4 + 0], r0 = sc.tris[(size_t)min(tri, num_tris - 1) * 4 + 1];
-        const float4 r1 = sc.tris[(size_t)min(tri, num_tris - 1) * 4 + 2], r2 = sc.tris[(size_t)min(tri, num_tris - 1) * 4 + 3];
-        if (most <= kDirectPairs) {
+        const int mine = holds ? tri : wave_first; // (lanes without a face have no pairs; any record will do)
+        const float4 pn = sc.tris[(size_t)mine * 4 + 0], r0 = sc.tris[(size_t)mine * 4 + 1];
+        const float4 r1 = sc.tris[(size_t)mine * 4 + 2], r2 = sc.tris[(size_t)mine * 4 + 3];
+        if (fshift == 6 && most <= kDirectPairs) {
             // every lane its own face: k-th pixel of the box, row by row
             int x = f.px0, y = row0;
             for (int k = 0; k < most; ++k) {
@@ -2074,11 +2080,19 @@ void launch_prep(const FrameConst &fc, const Workspace &ws, void *zero, size_t z
 // launch_compact; the tree walk behind it (launch_walk_closest) only does anything where the pass gave way to it.
 void launch_primary_faces(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, hipStream_t stream) {
     if (num_tris <= 0) return;
-    const unsigned blocks = (unsigned)((num_tris + 255) / 256);
+    // Faces per wave: 64, or down to 16 while that leaves fewer than 4096 waves (the chip holds about 7000 of this kernel).
+    // 69 K faces at 1080p, a frame alone: 42.6 us with 64, 34.4 with 32, 25.8 with 16, 23.1 with 8; at 4K 140 / 102 / 70 / 49.
+    // With frames in flight 16 is as fast as 64 or a shade faster, 8 and 4 cost 2-7 % (idle lanes while projecting).
+    static const int forced = getenv("RTAMD_RASTER_FACES_PER_WAVE_SHIFT") ? atoi(getenv("RTAMD_RASTER_FACES_PER_WAVE_SHIFT")) : -1; // experiment hook
+    int fshift = 6;
+    while (fshift > 4 && ((long long)num_tris >> fshift) < 4096) --fshift;
+    if (forced >= 2 && forced <= 6) fshift = forced;
+    const unsigned per_block = 4u << fshift;
+    const unsigned blocks = (unsigned)(((unsigned)num_tris + per_block - 1) / per_block);
     if (count)
-        face_raster_kernel<true><<<blocks, 256, 0, stream>>>(sc, fc, ws, num_tris);
+        face_raster_kernel<true><<<blocks, 256, 0, stream>>>(sc, fc, ws, num_tris, fshift);
     else
-        face_raster_kernel<false><<<blocks, 256, 0, stream>>>(sc, fc, ws, num_tris);
+        face_raster_kernel<false><<<blocks, 256, 0, stream>>>(sc, fc, ws, num_tris, fshift);
 }
 
 void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, bool cleared,
