@@ -460,6 +460,10 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     // one record per TriRecord, in the same (leaf) order: hits that are neighbours in space read neighbouring records,
     // and the shading kernels need no detour over the face index
     const int32_t num_records = (int32_t)bvh.tris.size();
+    if (bvh.tris.size() >= ((size_t)1 << 26)) { // the kernels address the 64-byte records by 32-bit byte offsets
+        rtamd_scene_destroy(s);
+        return fail(RTAMD_ERR_LIMIT, "%zu faces: at most %d are supported", bvh.tris.size(), (1 << 26) - 1);
+    }
     std::vector<ShadeRecord> shade((size_t)num_records);
     auto fill_shade = [&](int32_t i0, int32_t i1) {
         for (int32_t i = i0; i < i1; ++i) {
@@ -566,6 +570,8 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     if (!grids_on_device) {
         if (rc == RTAMD_OK) rc = upload(&s->d_grid_headers, grids.headers, &bytes);
         if (rc == RTAMD_OK) rc = upload(&s->d_grid_cells, grids.cell_start, &bytes);
+        // (two entries of padding: the kernel fetches a batch of three whatever the length of the list)
+        grids.entries.resize(grids.entries.size() + 2, ShadowGridEntry{});
         if (rc == RTAMD_OK) rc = upload(&s->d_grid_entries, grids.entries, &bytes);
     }
     if (rc != RTAMD_OK) {
@@ -601,7 +607,7 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     s->face_primary = primary_mode == RTAMD_PRIMARY_RAYS_AUTO && !faces_off;
     s->bin_primary = primary_mode == RTAMD_PRIMARY_RAYS_BINS || (primary_mode == RTAMD_PRIMARY_RAYS_AUTO && faces_off);
     s->bin_always = primary_mode == RTAMD_PRIMARY_RAYS_BINS;
-    s->info.shadow_grid_entries = !grids_usable ? 0 : grids_on_device ? dgrids.num_entries : (uint64_t)grids.entries.size();
+    s->info.shadow_grid_entries = !grids_usable ? 0 : grids_on_device ? dgrids.num_entries : (uint64_t)grids.entries.size() - 2 /* padding */;
     s->ds.num_lights = d->num_lights;
     s->ds.spl = d->samples_per_light;
     s->ds.num_spheres = d->num_spheres;

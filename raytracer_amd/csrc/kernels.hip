@@ -1526,12 +1526,16 @@ __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const Fr
                 const int begin = sc.grid_cells[cell], end = sc.grid_cells[cell + 1];
                 // a few candidates at a time (RT_SHADOW_BATCH): independent entry loads, then independent plane loads
                 for (int e = begin + RT_SHADOW_BATCH * sub; e < end && !blocked; e += RT_SHADOW_BATCH * split) {
+                    // (one address for the batch: the entry array is padded, so the fetch may run past the end of the list,
+                    // into the next list's entries, which are skipped below; records by 32-bit byte offsets from the base)
+                    const int2 *const ep = sc.grid_entries + e;
                     int2 ent[RT_SHADOW_BATCH];
 #pragma unroll
-                    for (int k = 0; k < RT_SHADOW_BATCH; ++k) ent[k] = sc.grid_entries[min(e + k, end - 1)];
+                    for (int k = 0; k < RT_SHADOW_BATCH; ++k) ent[k] = ep[k];
+                    const char *const records = (const char *)sc.tris;
                     float4 pn[RT_SHADOW_BATCH];
 #pragma unroll
-                    for (int k = 0; k < RT_SHADOW_BATCH; ++k) pn[k] = sc.tris[ent[k].x * 4 + 0];
+                    for (int k = 0; k < RT_SHADOW_BATCH; ++k) pn[k] = *(const float4 *)(records + ((unsigned)ent[k].x << 6));
                     bool behind = false;
 #pragma unroll
                     for (int k = 0; k < RT_SHADOW_BATCH; ++k) {
@@ -1545,9 +1549,10 @@ __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const Fr
                         const V3 n = mk(pn[k].x, pn[k].y, pn[k].z);
                         const float t = (pn[k].w - dot(o, n)) / dot(d, n);
                         if (!(t >= fc.t_eps && t <= tbest)) continue; // also rejects NaN (see file header)
-                        const float4 p0 = sc.tris[i * 4 + 1];
-                        const float4 p1 = sc.tris[i * 4 + 2];
-                        const float4 p2 = sc.tris[i * 4 + 3];
+                        const float4 *const rec = (const float4 *)(records + ((unsigned)i << 6));
+                        const float4 p0 = rec[1];
+                        const float4 p1 = rec[2];
+                        const float4 p2 = rec[3];
                         if (COUNT) ++w_edge;
                         const V3 v0 = mk(p0.x, p0.y, p0.z), v1 = mk(p1.x, p1.y, p1.z), v2 = mk(p2.x, p2.y, p2.z);
                         const V3 at = o + t * d;
