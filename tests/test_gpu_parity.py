@@ -568,6 +568,33 @@ def test_frames_rendered_in_bands_equal_whole_frames(name, size, kw):
     assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and got[3].rays_bounce == ref[3].rays_bounce
 
 
+def test_reflective_frames_beside_more_foreign_streams_than_hardware_queues():
+    """A reflective scene rendered on one stream while six foreign streams carry work of their own, under HIP's default of
+    four hardware queues: every frame runs entirely on its caller's stream (the library owns no streams and waits on no
+    event of another stream), so nothing can stall behind a queue it shares; the frames equal the one rendered alone."""
+    import torch
+
+    fly, _ = make_pair("reflect_test", width=160, height=120)
+    fly.set_params(max_reflections=3)
+    want = fly.render()
+    foreign = [torch.cuda.Stream() for _ in range(6)]
+    mine = torch.cuda.Stream()
+    a = [torch.rand((512, 512), device="cuda") for _ in foreign]
+    rgb = [torch.zeros((120, 160, 3), dtype=torch.float32, device="cuda") for _ in range(3)]
+    fid = torch.zeros((120, 160), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for turn in range(12):
+        for s, m in zip(foreign, a):
+            with torch.cuda.stream(s):
+                for _ in range(4):
+                    m = torch.tanh(m @ m * 1e-3)
+        fly.render_device(rgb[turn % 3], fid, stream=mine)
+    torch.cuda.synchronize()
+    for r in rgb:
+        assert np.array_equal(r.cpu().numpy().view(np.uint32), want["rgb"].view(np.uint32))
+    assert np.array_equal(fid.cpu().numpy(), want["face_id"])
+
+
 def test_device_ppm_quantisation_matches_the_file_writer(tmp_path):
     """rtamd_quantize_ppm gives the bytes of the reference's writePPMImage (utils/ppmIO.hpp:203), also at channel
     values of exactly k/255, above 1, and for lengths that are no multiple of four."""
