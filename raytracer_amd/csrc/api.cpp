@@ -570,8 +570,8 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     if (!grids_on_device) {
         if (rc == RTAMD_OK) rc = upload(&s->d_grid_headers, grids.headers, &bytes);
         if (rc == RTAMD_OK) rc = upload(&s->d_grid_cells, grids.cell_start, &bytes);
-        // (two entries of padding: the kernel fetches a batch of three whatever the length of the list)
-        grids.entries.resize(grids.entries.size() + 2, ShadowGridEntry{});
+        // (padding: the kernel fetches a batch of a few entries whatever the length of the list)
+        grids.entries.resize(grids.entries.size() + kShadowGridPadding, ShadowGridEntry{});
         if (rc == RTAMD_OK) rc = upload(&s->d_grid_entries, grids.entries, &bytes);
     }
     if (rc != RTAMD_OK) {
@@ -607,7 +607,7 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     s->face_primary = primary_mode == RTAMD_PRIMARY_RAYS_AUTO && !faces_off;
     s->bin_primary = primary_mode == RTAMD_PRIMARY_RAYS_BINS || (primary_mode == RTAMD_PRIMARY_RAYS_AUTO && faces_off);
     s->bin_always = primary_mode == RTAMD_PRIMARY_RAYS_BINS;
-    s->info.shadow_grid_entries = !grids_usable ? 0 : grids_on_device ? dgrids.num_entries : (uint64_t)grids.entries.size() - 2 /* padding */;
+    s->info.shadow_grid_entries = !grids_usable ? 0 : grids_on_device ? dgrids.num_entries : (uint64_t)grids.entries.size() - kShadowGridPadding;
     s->ds.num_lights = d->num_lights;
     s->ds.spl = d->samples_per_light;
     s->ds.num_spheres = d->num_spheres;

@@ -359,12 +359,12 @@ bool build_shadow_grids_device(const std::vector<TriRecord> &tris, const void *d
     // one cell-start array and one entry array for all samples
     int *d_cells = nullptr;
     int2 *d_entries = nullptr;
-    // (two entries of padding behind the last list: shadow_grid_kernel fetches a batch of three whatever a list's length)
-    if (!buf.get(&d_cells, (size_t)all_cells) || !buf.get(&d_entries, (size_t)std::max<long long>(all_entries, 1) + 2)) {
+    // (padding behind the last list: shadow_grid_kernel fetches a batch of entries whatever a list's length)
+    if (!buf.get(&d_cells, (size_t)all_cells) || !buf.get(&d_entries, (size_t)std::max<long long>(all_entries, 1) + kShadowGridPadding)) {
         why = "out of device memory";
         return false;
     }
-    GRID_TRY(hipMemset(d_entries + std::max<long long>(all_entries, 1) - 1, 0, 3 * sizeof(int2))); // the padding names record 0
+    GRID_TRY(hipMemset(d_entries + std::max<long long>(all_entries, 1) - 1, 0, (kShadowGridPadding + 1) * sizeof(int2))); // the padding names record 0
     long long cell_at = 0, entry_at = 0;
     for (const PerSample &ps : done) {
         GRID_TRY(hipMemcpy(d_cells + cell_at, ps.start, ((size_t)ps.cells + 1) * sizeof(int), hipMemcpyDeviceToDevice));

@@ -1465,6 +1465,7 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst 
 #ifndef RT_SHADOW_BATCH
 #define RT_SHADOW_BATCH 3
 #endif
+static_assert(RT_SHADOW_BATCH >= 1 && RT_SHADOW_BATCH <= 8, "the entry arrays are padded by seven entries (kShadowGridPadding in shadow_grid.hpp)");
 #ifndef RT_SHADOW_XCD
 #define RT_SHADOW_XCD 1
 #endif

@@ -29,6 +29,10 @@ struct ShadowGridHeader {
 };
 static_assert(sizeof(ShadowGridHeader) == 64, "ShadowGridHeader layout");
 
+// Entries of padding behind the last list of the entry array: the kernel fetches its batch of entries (three) with one
+// address, whatever the length of the list, and must find memory there.
+constexpr int kShadowGridPadding = 7;
+
 struct ShadowGridEntry {
     int32_t tri; // TriRecord index
     float zmax;  // farthest extent of the face along W, widened; a ray origin beyond it cannot see the face
