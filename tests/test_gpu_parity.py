@@ -523,7 +523,9 @@ def test_row_tile_parts_assemble_to_the_full_frame(parts, tile):
 
 @pytest.mark.parametrize("name,size,kw", [("reflect_test", (200, 203), dict(max_reflections=3)),
                                           ("toy", (96, 100), dict(ssaa_level=2, max_reflections=1)),
-                                          ("bunny", (333, 222), dict(max_reflections=0))])
+                                          ("bunny", (333, 222), dict(max_reflections=0)),
+                                          ("textured_quad", (150, 90), dict(max_reflections=1)),
+                                          ("glass", (128, 136), dict(max_reflections=2, background=(0.1, 0.2, 0.3)))])
 def test_frames_rendered_in_bands_equal_whole_frames(name, size, kw):
     """rtamd_scene_set_workspace_limit: a frame rendered band by band through work buffers of one band's size is the whole
     frame bit for bit, ray counts included, through both entry points and again once the launches are sized by feedback."""
