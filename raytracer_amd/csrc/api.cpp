@@ -96,7 +96,7 @@ struct rtamd_scene {
     int device = -1;
     int num_cus = 256;
     void *d_nodes = nullptr, *d_tris = nullptr, *d_shade = nullptr, *d_materials = nullptr;
-    void *d_tri_of_rank = nullptr, *d_cluster_box = nullptr;
+    void *d_tri_of_rank = nullptr, *d_cluster_box = nullptr, *d_planes = nullptr;
     void *d_light_pos = nullptr, *d_samples = nullptr, *d_spheres = nullptr, *d_texels = nullptr, *d_tex_info = nullptr;
     void *d_grid_headers = nullptr, *d_grid_cells = nullptr, *d_grid_entries = nullptr;
     DeviceScene ds{};
@@ -524,6 +524,11 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     if (rc == RTAMD_OK) rc = upload(&s->d_nodes, bvh.nodes4, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_tris, bvh.tris, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_shade, shade, &bytes);
+    // The plane of every record once more, 16 bytes apiece: a shadow ray tests the planes of all its candidates and the
+    // corners of few, and four planes share the 64-byte line that holds one whole record.
+    std::vector<float> planes((size_t)num_records * 4);
+    for (int32_t i = 0; i < num_records; ++i) std::memcpy(&planes[(size_t)i * 4], bvh.tris[(size_t)i].n, 16);
+    if (rc == RTAMD_OK) rc = upload(&s->d_planes, planes, &bytes);
     std::vector<int32_t> tri_of_rank((size_t)d->num_faces, -1); // face raster: the pixel keeps a rank, the shading wants the record
     for (int32_t i = 0; i < num_records; ++i) {
         const int32_t r = bvh.tris[(size_t)i].rank;
@@ -582,6 +587,7 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
 
     s->ds.nodes = (const float4 *)s->d_nodes;
     s->ds.tris = (const float4 *)s->d_tris;
+    s->ds.planes = (const float4 *)s->d_planes;
     s->ds.shade = (const float4 *)s->d_shade;
     s->ds.materials = (const float *)s->d_materials;
     s->ds.light_pos = (const float *)s->d_light_pos;
@@ -645,7 +651,7 @@ int rtamd_reference_face_rank(const rtamd_scene_desc *d, int32_t *rank_out) {
 
 int rtamd_scene_destroy(rtamd_scene *s) {
     if (!s) return RTAMD_OK;
-    void *bufs[] = {s->d_tri_of_rank, s->d_cluster_box, s->d_nodes, s->d_tris,  s->d_shade,  s->d_materials, s->d_light_pos, s->d_samples,
+    void *bufs[] = {s->d_tri_of_rank, s->d_cluster_box, s->d_planes, s->d_nodes, s->d_tris,  s->d_shade,  s->d_materials, s->d_light_pos, s->d_samples,
                     s->d_spheres, s->d_texels, s->d_tex_info, s->d_grid_headers, s->d_grid_cells, s->d_grid_entries,
                     s->d_rgb, s->d_face};
     (void)hipDeviceSynchronize(); // frames may still be in flight on the caller's streams

@@ -14,6 +14,7 @@ constexpr int kMaxStages = 64;      // (ssaa passes) * (max_reflections + 1) cou
 struct DeviceScene {
     const float4 *nodes;      // 8 x float4 per Bvh4Node
     const float4 *tris;       // 4 x float4 per TriRecord
+    const float4 *planes;     // (n, D) of every TriRecord once more, densely packed: what a test reads before it needs the corners
     const float4 *shade;      // 8 x float4 per ShadeRecord, indexed like tris
     const float *materials;   // 12 floats per material: ka, kd, ks, shininess, texture index (int bits), pad
     const float *texels;      // all textures back to back, 3 floats per texel

@@ -1466,6 +1466,15 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst 
 #define RT_SHADOW_BATCH 3
 #endif
 static_assert(RT_SHADOW_BATCH >= 1 && RT_SHADOW_BATCH <= 8, "the entry arrays are padded by seven entries (kShadowGridPadding in shadow_grid.hpp)");
+#ifndef RT_SHADOW_PLANES
+#define RT_SHADOW_PLANES 1
+#endif
+#ifndef RT_SHADOW_PIPE
+#define RT_SHADOW_PIPE 0
+#endif
+#ifndef RT_SHADOW_EDGES_TOGETHER
+#define RT_SHADOW_EDGES_TOGETHER 1
+#endif
 #ifndef RT_SHADOW_XCD
 #define RT_SHADOW_XCD 1
 #endif
@@ -1526,17 +1535,41 @@ __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const Fr
                 const int cell = first_cell + (int)fy * res + (int)fx;
                 const int begin = sc.grid_cells[cell], end = sc.grid_cells[cell + 1];
                 // a few candidates at a time (RT_SHADOW_BATCH): independent entry loads, then independent plane loads
+#if RT_SHADOW_PIPE
+                int2 ent_ahead[RT_SHADOW_BATCH];
+                {
+                    const int2 *const ep0 = sc.grid_entries + (begin + RT_SHADOW_BATCH * sub);
+#pragma unroll
+                    for (int k = 0; k < RT_SHADOW_BATCH; ++k) ent_ahead[k] = ep0[k];
+                }
+#endif
                 for (int e = begin + RT_SHADOW_BATCH * sub; e < end && !blocked; e += RT_SHADOW_BATCH * split) {
                     // (one address for the batch: the entry array is padded, so the fetch may run past the end of the list,
                     // into the next list's entries, which are skipped below; records by 32-bit byte offsets from the base)
                     const int2 *const ep = sc.grid_entries + e;
                     int2 ent[RT_SHADOW_BATCH];
+#if RT_SHADOW_PIPE
+#pragma unroll
+                    for (int k = 0; k < RT_SHADOW_BATCH; ++k) ent[k] = ent_ahead[k];
+#else
 #pragma unroll
                     for (int k = 0; k < RT_SHADOW_BATCH; ++k) ent[k] = ep[k];
+#endif
                     const char *const records = (const char *)sc.tris;
                     float4 pn[RT_SHADOW_BATCH];
 #pragma unroll
+#if RT_SHADOW_PLANES
+                    for (int k = 0; k < RT_SHADOW_BATCH; ++k) pn[k] = *(const float4 *)((const char *)sc.planes + ((unsigned)ent[k].x << 4));
+#else
                     for (int k = 0; k < RT_SHADOW_BATCH; ++k) pn[k] = *(const float4 *)(records + ((unsigned)ent[k].x << 6));
+#endif
+#if RT_SHADOW_PIPE
+                    {
+                        const int2 *const epn = ep + RT_SHADOW_BATCH * split; // (may run past the list: the array is padded)
+#pragma unroll
+                        for (int k = 0; k < RT_SHADOW_BATCH; ++k) ent_ahead[k] = epn[k];
+                    }
+#endif
                     bool behind = false;
 #pragma unroll
                     for (int k = 0; k < RT_SHADOW_BATCH; ++k) {
@@ -1557,9 +1590,18 @@ __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const Fr
                         if (COUNT) ++w_edge;
                         const V3 v0 = mk(p0.x, p0.y, p0.z), v1 = mk(p1.x, p1.y, p1.z), v2 = mk(p2.x, p2.y, p2.z);
                         const V3 at = o + t * d;
+#if RT_SHADOW_EDGES_TOGETHER
+                        // the three edge functions side by side and ONE branch: tested one after the other, the compiler
+                        // fetches the third corner only behind the first test, a second round trip per candidate
+                        const float e0 = dot(cross(v1 - v0, at - v0), n);
+                        const float e1 = dot(cross(v2 - v1, at - v1), n);
+                        const float e2 = dot(cross(v0 - v2, at - v2), n);
+                        if ((e0 < 0) | (e1 < 0) | (e2 < 0)) continue;
+#else
                         if (dot(cross(v1 - v0, at - v0), n) < 0) continue;
                         if (dot(cross(v2 - v1, at - v1), n) < 0) continue;
                         if (dot(cross(v0 - v2, at - v2), n) < 0) continue;
+#endif
                         blocked = true;
                     }
                     if (behind) break;
