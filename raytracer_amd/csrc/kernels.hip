@@ -48,6 +48,9 @@ namespace rtamd {
 
 namespace {
 
+#ifndef RT_KEEP_LOADS
+#define RT_KEEP_LOADS 1
+#endif
 constexpr int kSentinel = 0x7fffffff;
 
 enum WalkMode { kPrimary = 0, kQueue = 1, kShadow = 2 };
@@ -79,6 +82,16 @@ __device__ __forceinline__ float norm(V3 a) { return sqrtf(dot(a, a)); }
 // std::max / std::min as cwiseMax / cwiseMin apply them
 __device__ __forceinline__ float smax(float a, float b) { return a < b ? b : a; }
 __device__ __forceinline__ float smin(float a, float b) { return b < a ? b : a; }
+
+// Pins a fetched value where the source puts it.  Left alone, the compiler moves a load behind the first branch that does not
+// need its result (the corners of a face behind the plane test, a node's child references behind its box tests): fewer bytes
+// fetched, but one more round trip to memory on the path that does need them, and these kernels wait for memory, not for
+// bytes.  The empty statement claims to rewrite the registers, so everything fetched before it is fetched together.
+__device__ __forceinline__ void keep(float4 &v) {
+#if RT_KEEP_LOADS
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+#endif
+}
 
 __device__ __forceinline__ float *plane(float *base, int capacity, int k) { return base + (size_t)k * (size_t)capacity; }
 __device__ __forceinline__ const float *plane(const float *base, int capacity, int k) { return base + (size_t)k * (size_t)capacity; }
@@ -443,7 +456,8 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
                 const float4 ex4 = *(const float4 *)(nodes + (nb + offx)), fx4 = *(const float4 *)(nodes + ((nb + offx) ^ 16u));
                 const float4 ey4 = *(const float4 *)(nodes + (nb + offy)), fy4 = *(const float4 *)(nodes + ((nb + offy) ^ 16u));
                 const float4 ez4 = *(const float4 *)(nodes + (nb + offz)), fz4 = *(const float4 *)(nodes + ((nb + offz) ^ 16u));
-                const float4 chf = *(const float4 *)(nodes + (nb + 96u));
+                float4 chf = *(const float4 *)(nodes + (nb + 96u));
+                keep(chf);
                 if (COUNT) w_box += (unsigned)__float_as_int((*(const float4 *)(nodes + (nb + 112u))).x);
                 const int c0 = __float_as_int(chf.x), c1 = __float_as_int(chf.y), c2 = __float_as_int(chf.z), c3 = __float_as_int(chf.w);
                 float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
@@ -515,10 +529,11 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
                     k = 0;
                     ++qi;
                 }
-                const float4 pn = sc.tris[i * 4 + 0];
-                const float4 p0 = sc.tris[i * 4 + 1];
-                const float4 p1 = sc.tris[i * 4 + 2];
-                const float4 p2 = sc.tris[i * 4 + 3];
+                float4 pn = sc.tris[i * 4 + 0];
+                float4 p0 = sc.tris[i * 4 + 1];
+                float4 p1 = sc.tris[i * 4 + 2];
+                float4 p2 = sc.tris[i * 4 + 3];
+                keep(pn), keep(p0), keep(p1), keep(p2);
                 if (COUNT) ++w_plane;
                 const V3 n = mk(pn.x, pn.y, pn.z);
                 const float t = (pn.w - dot(o, n)) / dot(d, n);
@@ -741,7 +756,8 @@ __device__ __forceinline__ void walk_steal_body(const DeviceScene &sc, const Fra
                 const float4 ex4 = *(const float4 *)(nodes + (nb + rs.offx)), fx4 = *(const float4 *)(nodes + ((nb + rs.offx) ^ 16u));
                 const float4 ey4 = *(const float4 *)(nodes + (nb + rs.offy)), fy4 = *(const float4 *)(nodes + ((nb + rs.offy) ^ 16u));
                 const float4 ez4 = *(const float4 *)(nodes + (nb + rs.offz)), fz4 = *(const float4 *)(nodes + ((nb + rs.offz) ^ 16u));
-                const float4 chf = *(const float4 *)(nodes + (nb + 96u));
+                float4 chf = *(const float4 *)(nodes + (nb + 96u));
+                keep(chf);
                 if (COUNT) w_box += (unsigned)__float_as_int((*(const float4 *)(nodes + (nb + 112u))).x);
                 const int c0 = __float_as_int(chf.x), c1 = __float_as_int(chf.y), c2 = __float_as_int(chf.z), c3 = __float_as_int(chf.w);
                 float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
@@ -805,10 +821,11 @@ __device__ __forceinline__ void walk_steal_body(const DeviceScene &sc, const Fra
                         k = 0;
                         ++qi;
                     }
-                    const float4 pn = sc.tris[i * 4 + 0];
-                    const float4 p0 = sc.tris[i * 4 + 1];
-                    const float4 p1 = sc.tris[i * 4 + 2];
-                    const float4 p2 = sc.tris[i * 4 + 3];
+                    float4 pn = sc.tris[i * 4 + 0];
+                    float4 p0 = sc.tris[i * 4 + 1];
+                    float4 p1 = sc.tris[i * 4 + 2];
+                    float4 p2 = sc.tris[i * 4 + 3];
+                    keep(pn), keep(p0), keep(p1), keep(p2);
                     if (COUNT) ++w_plane;
                     const V3 n = mk(pn.x, pn.y, pn.z);
                     const float t = (pn.w - dot(o, n)) / dot(d, n);
@@ -1460,21 +1477,13 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst 
 // faces' farthest extent along the direction: the scan ends at the first face that lies wholly behind the
 // ray's origin, or at the first face that blocks the sample.
 // ---------------------------------------------------------------------------------------------
-// Candidates per round trip in shadow_grid_kernel.  Three: 70 VGPRs, seven waves per SIMD (four: 80 and six, 1-3 %
-// slower; two: eight waves, but the chains get too long; six: four waves, 8-25 % slower).
+// Candidates per round trip in shadow_grid_kernel.  Four: 62 VGPRs, still eight waves per SIMD (three: 54 registers and one
+// more trip through the loop for many waves, 1.5 % slower; with the packed arithmetic of the SLP vectoriser, which the
+// Makefile turns off, four cost 80 registers and lost to three).
 #ifndef RT_SHADOW_BATCH
-#define RT_SHADOW_BATCH 3
+#define RT_SHADOW_BATCH 4
 #endif
 static_assert(RT_SHADOW_BATCH >= 1 && RT_SHADOW_BATCH <= 8, "the entry arrays are padded by seven entries (kShadowGridPadding in shadow_grid.hpp)");
-#ifndef RT_SHADOW_PLANES
-#define RT_SHADOW_PLANES 1
-#endif
-#ifndef RT_SHADOW_PIPE
-#define RT_SHADOW_PIPE 0
-#endif
-#ifndef RT_SHADOW_EDGES_TOGETHER
-#define RT_SHADOW_EDGES_TOGETHER 1
-#endif
 #ifndef RT_SHADOW_XCD
 #define RT_SHADOW_XCD 1
 #endif
@@ -1535,41 +1544,17 @@ __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const Fr
                 const int cell = first_cell + (int)fy * res + (int)fx;
                 const int begin = sc.grid_cells[cell], end = sc.grid_cells[cell + 1];
                 // a few candidates at a time (RT_SHADOW_BATCH): independent entry loads, then independent plane loads
-#if RT_SHADOW_PIPE
-                int2 ent_ahead[RT_SHADOW_BATCH];
-                {
-                    const int2 *const ep0 = sc.grid_entries + (begin + RT_SHADOW_BATCH * sub);
-#pragma unroll
-                    for (int k = 0; k < RT_SHADOW_BATCH; ++k) ent_ahead[k] = ep0[k];
-                }
-#endif
                 for (int e = begin + RT_SHADOW_BATCH * sub; e < end && !blocked; e += RT_SHADOW_BATCH * split) {
                     // (one address for the batch: the entry array is padded, so the fetch may run past the end of the list,
                     // into the next list's entries, which are skipped below; records by 32-bit byte offsets from the base)
                     const int2 *const ep = sc.grid_entries + e;
                     int2 ent[RT_SHADOW_BATCH];
-#if RT_SHADOW_PIPE
-#pragma unroll
-                    for (int k = 0; k < RT_SHADOW_BATCH; ++k) ent[k] = ent_ahead[k];
-#else
 #pragma unroll
                     for (int k = 0; k < RT_SHADOW_BATCH; ++k) ent[k] = ep[k];
-#endif
                     const char *const records = (const char *)sc.tris;
                     float4 pn[RT_SHADOW_BATCH];
 #pragma unroll
-#if RT_SHADOW_PLANES
                     for (int k = 0; k < RT_SHADOW_BATCH; ++k) pn[k] = *(const float4 *)((const char *)sc.planes + ((unsigned)ent[k].x << 4));
-#else
-                    for (int k = 0; k < RT_SHADOW_BATCH; ++k) pn[k] = *(const float4 *)(records + ((unsigned)ent[k].x << 6));
-#endif
-#if RT_SHADOW_PIPE
-                    {
-                        const int2 *const epn = ep + RT_SHADOW_BATCH * split; // (may run past the list: the array is padded)
-#pragma unroll
-                        for (int k = 0; k < RT_SHADOW_BATCH; ++k) ent_ahead[k] = epn[k];
-                    }
-#endif
                     bool behind = false;
 #pragma unroll
                     for (int k = 0; k < RT_SHADOW_BATCH; ++k) {
@@ -1590,18 +1575,12 @@ __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const Fr
                         if (COUNT) ++w_edge;
                         const V3 v0 = mk(p0.x, p0.y, p0.z), v1 = mk(p1.x, p1.y, p1.z), v2 = mk(p2.x, p2.y, p2.z);
                         const V3 at = o + t * d;
-#if RT_SHADOW_EDGES_TOGETHER
                         // the three edge functions side by side and ONE branch: tested one after the other, the compiler
                         // fetches the third corner only behind the first test, a second round trip per candidate
                         const float e0 = dot(cross(v1 - v0, at - v0), n);
                         const float e1 = dot(cross(v2 - v1, at - v1), n);
                         const float e2 = dot(cross(v0 - v2, at - v2), n);
                         if ((e0 < 0) | (e1 < 0) | (e2 < 0)) continue;
-#else
-                        if (dot(cross(v1 - v0, at - v0), n) < 0) continue;
-                        if (dot(cross(v2 - v1, at - v1), n) < 0) continue;
-                        if (dot(cross(v0 - v2, at - v2), n) < 0) continue;
-#endif
                         blocked = true;
                     }
                     if (behind) break;
