@@ -1861,18 +1861,28 @@ __device__ __forceinline__ void shade_body(const DeviceScene &sc, const FrameCon
 
     const V3 P = mk(plane(hl.p, ws.capacity, 0)[idx], plane(hl.p, ws.capacity, 1)[idx], plane(hl.p, ws.capacity, 2)[idx]);
     // getLightIntensity, src/flyscene.cpp:870-896: share of unoccluded samples per light, summed, capped at 1
+    // (the hit's other fields are asked for here, with the first samples: everything that depends on the index alone in
+    // one round trip; the samples four at a time, not one fetch after the other -- they are 0 or 1, so any order sums alike)
+    const int slot = hl.slot[idx];
+    const int tri = hl.tri[idx];
+    const int child = spawn ? hl.child[idx] : -1;
     float li = 0.0f;
     for (int l = 0; l < sc.num_lights; ++l) {
+        const uint8_t *const seen = ws.clear[depth & 1] + (size_t)(l * sc.spl) * ws.capacity + idx;
         float reaching = 0.0f;
-        for (int k = 0; k < sc.spl; ++k) reaching += (float)ws.clear[depth & 1][(size_t)(l * sc.spl + k) * ws.capacity + idx];
+        int k = 0;
+        for (; k + 4 <= sc.spl; k += 4) {
+            const uint8_t b0 = seen[(size_t)k * ws.capacity], b1 = seen[(size_t)(k + 1) * ws.capacity];
+            const uint8_t b2 = seen[(size_t)(k + 2) * ws.capacity], b3 = seen[(size_t)(k + 3) * ws.capacity];
+            reaching += (float)b0, reaching += (float)b1, reaching += (float)b2, reaching += (float)b3;
+        }
+        for (; k < sc.spl; ++k) reaching += (float)seen[(size_t)k * ws.capacity];
         li += reaching / (float)sc.spl;
     }
     li = smin(li, 1.0f);
     const V3 LI = mk(li, li, li);
 
     // the ray that produced this hit
-    const int slot = hl.slot[idx];
-    const int tri = hl.tri[idx];
     V3 ro, T, ks = mk(0, 0, 0);
     int pix;
     if (PRIMARY) {
@@ -1893,8 +1903,9 @@ __device__ __forceinline__ void shade_body(const DeviceScene &sc, const FrameCon
     if (tri < 0) {
         local = mk(0.7f, 0.9f, 0.0f); // sphere, :463-465
     } else {
-        const float4 s0 = sc.shade[tri * kShadeRecordQuads + 0], s1 = sc.shade[tri * kShadeRecordQuads + 1], s2 = sc.shade[tri * kShadeRecordQuads + 2];
-        const float4 s3 = sc.shade[tri * kShadeRecordQuads + 3], s4 = sc.shade[tri * kShadeRecordQuads + 4], s5 = sc.shade[tri * kShadeRecordQuads + 5];
+        float4 s0 = sc.shade[tri * kShadeRecordQuads + 0], s1 = sc.shade[tri * kShadeRecordQuads + 1], s2 = sc.shade[tri * kShadeRecordQuads + 2];
+        float4 s3 = sc.shade[tri * kShadeRecordQuads + 3], s4 = sc.shade[tri * kShadeRecordQuads + 4], s5 = sc.shade[tri * kShadeRecordQuads + 5];
+        keep(s0), keep(s1), keep(s2), keep(s3), keep(s4), keep(s5); // (the whole record at once, not the material index first)
         const V3 v0 = mk(s0.x, s0.y, s0.z), v1 = mk(s0.w, s1.x, s1.y), v2 = mk(s1.z, s1.w, s2.x);
         const V3 n0 = mk(s2.y, s2.z, s2.w), n1 = mk(s3.x, s3.y, s3.z), n2 = mk(s3.w, s4.x, s4.y);
         const int mat = __float_as_int(s5.y);
@@ -1955,7 +1966,6 @@ __device__ __forceinline__ void shade_body(const DeviceScene &sc, const FrameCon
 
     // throughput of the reflection ray spawned from this hit: local + C_next * ks * LI, :637,645
     if (spawn) {
-        const int child = hl.child[idx];
         if (child >= 0) {
             const V3 nT = cmul(cmul(T, ks), LI);
             float *q = ws.queue[(depth + 1) % 3];
