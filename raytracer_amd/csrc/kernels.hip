@@ -48,6 +48,9 @@ namespace rtamd {
 
 namespace {
 
+#ifndef RT_RASTER_PAIRS
+#define RT_RASTER_PAIRS 2
+#endif
 #ifndef RT_KEEP_LOADS
 #define RT_KEEP_LOADS 1
 #endif
@@ -149,13 +152,15 @@ __device__ __forceinline__ bool slot_pixel_of_wave(const FrameConst &fc, int slo
 // Direction of the primary ray of pixel (x, local row): camera_direction with the two screen coordinates -- which
 // depend on the column alone and on the row alone -- read from the tables that prep_kernel filled for this pass
 // with camera_direction's own expressions (double-precision divisions once per column and row, not per pixel).
-__device__ __forceinline__ V3 primary_direction(const FrameConst &fc, const Workspace &ws, int x, int row) {
-    const float nx = ws.dir_x[x], ny = ws.dir_y[row];
+__device__ __forceinline__ V3 primary_direction_of(const FrameConst &fc, float nx, float ny) {
     const float nz = -1.0f;
     const float *m = fc.inv_view;
     const V3 w = mk(m[3] + (m[0] * nx + m[1] * ny + m[2] * nz), m[7] + (m[4] * nx + m[5] * ny + m[6] * nz),
                     m[11] + (m[8] * nx + m[9] * ny + m[10] * nz));
     return normalized(w - mk(fc.origin[0], fc.origin[1], fc.origin[2]));
+}
+__device__ __forceinline__ V3 primary_direction(const FrameConst &fc, const Workspace &ws, int x, int row) {
+    return primary_direction_of(fc, ws.dir_x[x], ws.dir_y[row]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1301,6 +1306,62 @@ __device__ __forceinline__ void raster_pair(const FrameConst &fc, const Workspac
     if (ws.prefilled) ws.tile_flag[(lr >> 3) * fc.tiles_x + (x >> 3)] = 1; // the compaction kernel then looks at flagged tiles only
 }
 
+// Several pairs of one lane side by side: the table entries of all their pixels in one round trip, then all keys in the
+// next (taken one after the other, a lane's pairs are a chain of two dependent fetches each).  Same tests, same atomics.
+struct FaceRec {
+    float4 pn, r0, r1, r2;
+};
+template <bool COUNT, int U>
+__device__ __forceinline__ void raster_pairs(const FrameConst &fc, const Workspace &ws, const FaceRec (&f)[U], const int (&x)[U], const int (&lr)[U],
+                                             const bool (&on)[U], unsigned &w_plane, unsigned &w_edge) {
+    const V3 o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
+    float nx[U], ny[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        nx[u] = ny[u] = 0.0f;
+        if (on[u]) nx[u] = ws.dir_x[x[u]], ny[u] = ws.dir_y[lr[u]];
+    }
+#if RT_KEEP_LOADS
+#pragma unroll
+    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(nx[u]), "+v"(ny[u]));
+#endif
+    V3 d[U];
+    float t[U];
+    bool go[U];
+    unsigned long long seen[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        d[u] = primary_direction_of(fc, nx[u], ny[u]);
+        if (COUNT) w_plane += (unsigned)on[u];
+        const V3 n = mk(f[u].pn.x, f[u].pn.y, f[u].pn.z);
+        t[u] = (f[u].pn.w - dot(o, n)) / dot(d[u], n);
+        go[u] = on[u] && (t[u] >= fc.t_eps && t[u] <= FLT_MAX); // also rejects NaN (see file header)
+    }
+    // what the pixels hold already (possibly a moment ago: a key only ever gets nearer) spares the edge tests of faces behind it
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        seen[u] = 0ull;
+        if (go[u]) seen[u] = ws.pix_key[(size_t)lr[u] * (size_t)fc.width + (size_t)x[u]];
+    }
+#if RT_KEEP_LOADS
+#pragma unroll
+    for (int u = 0; u < U; ++u) asm volatile("" : "+v"(seen[u]));
+#endif
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!go[u] || (seen[u] != 0ull && t[u] > __int_as_float((int)(unsigned)(~seen[u] >> 32)))) continue;
+        if (COUNT) ++w_edge;
+        const V3 n = mk(f[u].pn.x, f[u].pn.y, f[u].pn.z);
+        const V3 v0 = mk(f[u].r0.x, f[u].r0.y, f[u].r0.z), v1 = mk(f[u].r1.x, f[u].r1.y, f[u].r1.z), v2 = mk(f[u].r2.x, f[u].r2.y, f[u].r2.z);
+        const V3 hp = o + t[u] * d[u];
+        if (dot(cross(v1 - v0, hp - v0), n) < 0) continue;
+        if (dot(cross(v2 - v1, hp - v1), n) < 0) continue;
+        if (dot(cross(v0 - v2, hp - v2), n) < 0) continue;
+        atomicMax(ws.pix_key + ((size_t)lr[u] * (size_t)fc.width + (size_t)x[u]), ~hit_key(t[u], __float_as_int(f[u].r1.w)));
+        if (ws.prefilled) ws.tile_flag[(lr[u] >> 3) * fc.tiles_x + (x[u] >> 3)] = 1; // the compaction kernel then looks at flagged tiles only
+    }
+}
+
 template <bool COUNT>
 // `fshift`: a wave takes 1 << fshift faces (6: one per lane).  A mesh of few faces makes few waves -- 69 K faces are 1085
 // waves of 64, a seventh of what the chip holds, each with hundreds of pairs to step through one batch after the other -- so
@@ -1347,10 +1408,26 @@ __global__ __launch_bounds__(256) void face_raster_kernel(DeviceScene sc, FrameC
         if (fshift == 6 && most <= kDirectPairs) {
             // every lane its own face: k-th pixel of the box, row by row
             int x = f.px0, y = row0;
+#if RT_RASTER_PAIRS > 1
+            FaceRec rec[RT_RASTER_PAIRS]; // (RT_RASTER_PAIRS pixels of the lane's own face per trip)
+#pragma unroll
+            for (int u = 0; u < RT_RASTER_PAIRS; ++u) rec[u].pn = pn, rec[u].r0 = r0, rec[u].r1 = r1, rec[u].r2 = r2;
+            for (int k = 0; k < most; k += RT_RASTER_PAIRS) {
+                int px[RT_RASTER_PAIRS], pr[RT_RASTER_PAIRS];
+                bool on[RT_RASTER_PAIRS];
+#pragma unroll
+                for (int u = 0; u < RT_RASTER_PAIRS; ++u) {
+                    px[u] = x, pr[u] = y, on[u] = k + u < count;
+                    if (++x > f.px1) x = f.px0, ++y;
+                }
+                raster_pairs<COUNT, RT_RASTER_PAIRS>(fc, ws, rec, px, pr, on, w_plane, w_edge);
+            }
+#else
             for (int k = 0; k < most; ++k) {
                 if (k < count) raster_pair<COUNT>(fc, ws, pn, r0, r1, r2, x, y, w_plane, w_edge);
                 if (++x > f.px1) x = f.px0, ++y;
             }
+#endif
         } else {
             s_rec[wave][0][lane] = pn, s_rec[wave][1][lane] = r0, s_rec[wave][2][lane] = r1, s_rec[wave][3][lane] = r2;
             s_box[wave][lane] = make_int4(f.px0, row0, max(w, 1), (int)(w <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / (unsigned long long)w)));
@@ -1362,6 +1439,36 @@ __global__ __launch_bounds__(256) void face_raster_kernel(DeviceScene sc, FrameC
             const int total = __shfl(incl, 63, 64);
             s_off[wave][lane] = incl - count;
             wave_sync();
+#if RT_RASTER_PAIRS > 1
+            for (int j0 = 0; j0 < total; j0 += 64 * RT_RASTER_PAIRS) {
+                // several pairs per lane and trip: pairs j0 + lane, j0 + 64 + lane, ...
+                FaceRec rec[RT_RASTER_PAIRS];
+                int px[RT_RASTER_PAIRS], pr[RT_RASTER_PAIRS];
+                bool on[RT_RASTER_PAIRS];
+#pragma unroll
+                for (int u = 0; u < RT_RASTER_PAIRS; ++u) {
+                    const int j = j0 + 64 * u + lane;
+                    on[u] = j < total;
+                    const int jc = on[u] ? j : 0;
+                    // the face of pair j: the last one whose first pair is <= j (faces without pixels share their successor's number)
+                    int lo = 0, hi = 63;
+#pragma unroll
+                    for (int step = 0; step < 6; ++step) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (s_off[wave][mid] <= jc)
+                            lo = mid;
+                        else
+                            hi = mid - 1;
+                    }
+                    const int4 box = s_box[wave][lo];
+                    const unsigned k = (unsigned)(jc - s_off[wave][lo]);
+                    const unsigned row = fast_div(k, (unsigned)box.z, (unsigned)box.w);
+                    px[u] = box.x + (int)(k - row * (unsigned)box.z), pr[u] = box.y + (int)row;
+                    rec[u].pn = s_rec[wave][0][lo], rec[u].r0 = s_rec[wave][1][lo], rec[u].r1 = s_rec[wave][2][lo], rec[u].r2 = s_rec[wave][3][lo];
+                }
+                raster_pairs<COUNT, RT_RASTER_PAIRS>(fc, ws, rec, px, pr, on, w_plane, w_edge);
+            }
+#else
             for (int j0 = 0; j0 < total; j0 += 64) {
                 const int j = j0 + lane;
                 if (j < total) {
@@ -1382,6 +1489,7 @@ __global__ __launch_bounds__(256) void face_raster_kernel(DeviceScene sc, FrameC
                                        box.y + (int)row, w_plane, w_edge);
                 }
             }
+#endif
         }
     }
     if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 2);
