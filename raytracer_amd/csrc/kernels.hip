@@ -1965,6 +1965,14 @@ __device__ __forceinline__ void shade_body(const DeviceScene &sc, const FrameCon
         ws.stage_feedback[2 * stage + 1] = ws.stage[stage].next + 1;
     }
     const HitList hl = ws.hits[depth & 1];
+    // the lights' positions once per workgroup (read per hit from global memory they are a fetch per light, one after the other)
+    constexpr int kLdsLights = 64;
+    __shared__ float s_light[3 * kLdsLights];
+    const bool lights_in_lds = sc.num_lights <= kLdsLights;
+    if (lights_in_lds) {
+        for (int i = (int)threadIdx.x; i < 3 * sc.num_lights; i += 256) s_light[i] = sc.light_pos[i];
+        __syncthreads();
+    }
     for (int idx = block * 256 + (int)threadIdx.x; idx < nhits; idx += nblocks * 256) {
 
     const V3 P = mk(plane(hl.p, ws.capacity, 0)[idx], plane(hl.p, ws.capacity, 1)[idx], plane(hl.p, ws.capacity, 2)[idx]);
@@ -1975,17 +1983,40 @@ __device__ __forceinline__ void shade_body(const DeviceScene &sc, const FrameCon
     const int tri = hl.tri[idx];
     const int child = spawn ? hl.child[idx] : -1;
     float li = 0.0f;
-    for (int l = 0; l < sc.num_lights; ++l) {
-        const uint8_t *const seen = ws.clear[depth & 1] + (size_t)(l * sc.spl) * ws.capacity + idx;
-        float reaching = 0.0f;
-        int k = 0;
-        for (; k + 4 <= sc.spl; k += 4) {
-            const uint8_t b0 = seen[(size_t)k * ws.capacity], b1 = seen[(size_t)(k + 1) * ws.capacity];
-            const uint8_t b2 = seen[(size_t)(k + 2) * ws.capacity], b3 = seen[(size_t)(k + 3) * ws.capacity];
-            reaching += (float)b0, reaching += (float)b1, reaching += (float)b2, reaching += (float)b3;
+    if (sc.spl >= 4) {
+        for (int l = 0; l < sc.num_lights; ++l) {
+            const uint8_t *const seen = ws.clear[depth & 1] + (size_t)(l * sc.spl) * ws.capacity + idx;
+            float reaching = 0.0f;
+            int k = 0;
+            for (; k + 4 <= sc.spl; k += 4) {
+                const uint8_t b0 = seen[(size_t)k * ws.capacity], b1 = seen[(size_t)(k + 1) * ws.capacity];
+                const uint8_t b2 = seen[(size_t)(k + 2) * ws.capacity], b3 = seen[(size_t)(k + 3) * ws.capacity];
+                reaching += (float)b0, reaching += (float)b1, reaching += (float)b2, reaching += (float)b3;
+            }
+            for (; k < sc.spl; ++k) reaching += (float)seen[(size_t)k * ws.capacity];
+            li += reaching / (float)sc.spl;
         }
-        for (; k < sc.spl; ++k) reaching += (float)seen[(size_t)k * ws.capacity];
-        li += reaching / (float)sc.spl;
+    } else {
+        // few samples per light (hard shadows of many lights): four fetches at a time across the lights, summed light by
+        // light in the same order
+        const uint8_t *const seen = ws.clear[depth & 1] + idx;
+        const int nshadow = sc.num_lights * sc.spl;
+        float reaching = 0.0f;
+        int of_light = 0;
+        for (int m0 = 0; m0 < nshadow; m0 += 4) {
+            uint8_t b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b[u] = m0 + u < nshadow ? seen[(size_t)(m0 + u) * ws.capacity] : (uint8_t)0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (m0 + u >= nshadow) break;
+                reaching += (float)b[u];
+                if (++of_light == sc.spl) {
+                    li += reaching / (float)sc.spl;
+                    reaching = 0.0f, of_light = 0;
+                }
+            }
+        }
     }
     li = smin(li, 1.0f);
     const V3 LI = mk(li, li, li);
@@ -2048,7 +2079,8 @@ __device__ __forceinline__ void shade_body(const DeviceScene &sc, const FrameCon
             }
             local = mk(0.0f, 0.0f, 0.0f);
             for (int l = 0; l < sc.num_lights; ++l) {
-                const V3 lp = mk(sc.light_pos[3 * l], sc.light_pos[3 * l + 1], sc.light_pos[3 * l + 2]);
+                const V3 lp = lights_in_lds ? mk(s_light[3 * l], s_light[3 * l + 1], s_light[3 * l + 2])
+                                            : mk(sc.light_pos[3 * l], sc.light_pos[3 * l + 1], sc.light_pos[3 * l + 2]);
                 const V3 L = normalized(lp - P);                          // :507
                 const V3 ambient = cmul(LI, ka);                          // :510
                 const float cos1 = fmaxf(0.0f, dot(L, N));                // :513
