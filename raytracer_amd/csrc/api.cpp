@@ -940,7 +940,7 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
                     if (bins_ok) launch_primary_bins(count, s->ds, fc, ws_frame, s->info.num_device_faces, /*cleared=*/true, stream);
                     // the tree walk behind them runs only where the pass gives way to it; the same view did not before
                     if (!ws_frame.bins_expected) launch_walk_closest(true, count, s->ds, fc, ws_frame, stage, 0, -1, stream);
-                    launch_compact(true, s->ds, fc, ws_frame, stage, 0, spawn, false, rgb, face_id, t_hit, -1, stream);
+                    launch_compact(true, s->ds, fc, ws_frame, stage, 0, spawn, false, rgb, face_id, t_hit, -1, stream, expect_hits[(size_t)stage]);
                 }
                 const int hits_here = expect_hits[(size_t)stage], rays_next = expect_next[(size_t)stage];
                 if (spawn && can_fuse_shadow_walk(s->ds, fc)) {
@@ -966,7 +966,8 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
                 launch_walk_closest(d == 0, count, s->ds, fc, ws_frame, stage, d, d > 0 ? expect_next[(size_t)stage - 1] : -1, stream); // after the bins: only on their overflow
                 if ((rc = end()) != RTAMD_OK) return rc;
                 if ((rc = begin(2)) != RTAMD_OK) return rc;
-                launch_compact(d == 0, s->ds, fc, ws_frame, stage, d, spawn, deep_bg && d > 0, rgb, face_id, t_hit, d > 0 ? expect_next[(size_t)stage - 1] : -1, stream);
+                launch_compact(d == 0, s->ds, fc, ws_frame, stage, d, spawn, deep_bg && d > 0, rgb, face_id, t_hit, d > 0 ? expect_next[(size_t)stage - 1] : -1, stream,
+                               d == 0 ? expect_hits[(size_t)stage] : -1);
                 if ((rc = end()) != RTAMD_OK) return rc;
                 // ---- shadow rays
                 if (nshadow > 0) {

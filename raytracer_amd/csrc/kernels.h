@@ -23,7 +23,7 @@ void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc
 void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth,
                          int expect, hipStream_t stream);
 void launch_compact(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, bool spawn,
-                    bool list_misses, float *rgb, int32_t *face_id, float *t_hit, int expect, hipStream_t stream);
+                    bool list_misses, float *rgb, int32_t *face_id, float *t_hit, int expect, hipStream_t stream, int expect_hits = -1);
 void launch_walk_shadow(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, int expect,
                         hipStream_t stream);
 void launch_shade(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, bool spawn, float *rgb,

@@ -2352,16 +2352,24 @@ void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const 
 }
 
 void launch_compact(bool primary, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, bool spawn,
-                    bool list_misses, float *rgb, int32_t *face_id, float *t_hit, int expect, hipStream_t stream) {
+                    bool list_misses, float *rgb, int32_t *face_id, float *t_hit, int expect, hipStream_t stream, int expect_hits) {
     const int total_static = fc.tiles_x * fc.tiles_y * 64;
     long long slots = primary ? total_static : ws.capacity;
     if (!primary && expect >= 0) slots = std::min(slots, with_margin(expect));
+    // Slots per workgroup (one atomic per list and workgroup): 512 for small images, which need the workgroups to fill the chip;
+    // 2048 for large ones where most workgroups only step over tiles nothing was hit in; 1024 for large ones with hits in a
+    // quarter of the pixels or more (what earlier frames of the view reported: `expect_hits`), where a thread's segments,
+    // taken one after the other, are a long chain of fetches (1.1 M-face field at 4K: this kernel 0.144 -> 0.118 ms).
     const bool large = slots > (4 << 20);
-    const int per_block = 256 * (large ? 8 : 2);
+    const bool dense = primary && expect_hits >= 0 && 4ll * expect_hits >= slots;
+    const int segments = !large ? 2 : dense ? 4 : 8;
+    const int per_block = 256 * segments;
     const int blocks = (int)((slots + per_block - 1) / per_block);
     if (primary) {
-        if (large)
+        if (segments == 8)
             compact_kernel<true, 8><<<blocks, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, 0, rgb, face_id, t_hit, total_static);
+        else if (segments == 4)
+            compact_kernel<true, 4><<<blocks, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, 0, rgb, face_id, t_hit, total_static);
         else
             compact_kernel<true, 2><<<blocks, 256, 0, stream>>>(sc, fc, ws, stage, depth, spawn, 0, rgb, face_id, t_hit, total_static);
     } else {
