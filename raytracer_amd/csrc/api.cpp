@@ -561,7 +561,7 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     if (rc == RTAMD_OK && grids_on_device) {
         const double tg0 = now_ms();
         std::string why;
-        if (build_shadow_grids_device(bvh.tris, s->d_tris, d->light_samples, d->num_lights * d->samples_per_light, shadow_grid_density(), dgrids, why)) {
+        if (build_shadow_grids_device(bvh.tris, s->d_tris, d->light_samples, d->num_lights * d->samples_per_light, shadow_grid_density(bvh.tris.size()), dgrids, why)) {
             s->d_grid_cells = dgrids.d_cell_start, s->d_grid_entries = dgrids.d_entries;
             bytes += dgrids.num_cells * 4 + dgrids.num_entries * sizeof(ShadowGridEntry);
             rc = upload(&s->d_grid_headers, dgrids.headers, &bytes);

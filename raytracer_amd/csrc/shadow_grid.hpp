@@ -56,7 +56,7 @@ struct DeviceShadowGrids {
 // tris: host copy of the records d_tris holds on the device.  false (with a reason): build on the host instead.
 bool build_shadow_grids_device(const std::vector<TriRecord> &tris, const void *d_tris, const float *samples, int num_samples, double density,
                                DeviceShadowGrids &out, std::string &why);
-double shadow_grid_density(); // cells per face
+double shadow_grid_density(size_t num_faces); // cells per face for a mesh of that many faces
 
 // ---- which cells of its box a face really needs (shared by the host and the device builder: same lists) ----
 // The box of a triangle holds about twice the cells the triangle touches.  A cell is left out when its rectangle,
