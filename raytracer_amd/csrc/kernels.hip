@@ -1496,7 +1496,8 @@ __global__ __launch_bounds__(256) void face_raster_kernel(DeviceScene sc, FrameC
 }
 
 // Candidates per round trip in raster_kernel.  Two: 70 VGPRs and seven waves per SIMD; four take 84 and five waves,
-// which costs more than the longer chains of dependent loads (bunny at 4K 6 %, 1.1 M-face field 3 %).
+// which costs more than the longer chains of dependent loads (bunny at 4K 6 %, 1.1 M-face field 3 %).  (Measured while the
+// SLP vectoriser was on for this file; this pass runs only behind RTAMD_PRIMARY_RAYS_BINS and was not measured again.)
 #ifndef RT_RASTER_BATCH
 #define RT_RASTER_BATCH 2
 #endif
@@ -1840,7 +1841,8 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
             const int mat = __float_as_int(sc.shade[tri * kShadeRecordQuads + 5].y);
             if (mat >= 0 && mat < sc.num_materials) {
                 const float *mp = sc.materials + kMaterialFloats * mat;
-                go = mp[6] > fc.refl_thresh || mp[7] > fc.refl_thresh || mp[8] > fc.refl_thresh; // :631-632
+                const float k0 = mp[6], k1 = mp[7], k2 = mp[8]; // (fetched together: one round trip, not up to three)
+                go = (k0 > fc.refl_thresh) | (k1 > fc.refl_thresh) | (k2 > fc.refl_thresh); // :631-632
             }
         }
         tri_of[j] = tri;
