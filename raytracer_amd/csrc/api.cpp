@@ -588,6 +588,7 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     s->ds.nodes = (const float4 *)s->d_nodes;
     s->ds.tris = (const float4 *)s->d_tris;
     s->ds.planes = (const float4 *)s->d_planes;
+    s->ds.num_records = num_records;
     s->ds.shade = (const float4 *)s->d_shade;
     s->ds.materials = (const float *)s->d_materials;
     s->ds.light_pos = (const float *)s->d_light_pos;

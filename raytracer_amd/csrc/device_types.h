@@ -33,6 +33,7 @@ struct DeviceScene {
     int32_t use_grids;
     // the (up to) sixteen grandchildren of the root, where the lanes of a shared ray start (0x7fffffff: none)
     int32_t start16[16];
+    int32_t num_records; // TriRecords (= planes = shading records)
 };
 
 // Per-launch constants (camera + the reference's macros).
