@@ -241,11 +241,12 @@ __device__ __forceinline__ void flush_work(unsigned a, unsigned b, unsigned c, W
 #ifndef RT_LDS_STACK
 #define RT_LDS_STACK 8
 #endif
-// Waves per SIMD the walkers (and the launch the bounce walk shares with the shadow rays) are compiled for.  Seven: 71
-// registers, nothing spilled, and 5.3 KB of LDS per wave still fit seven times four into a CU's 160 KB (six: 3 % slower with
-// frames in flight; eight: 64 registers, the LDS then allows seven anyway).
+// Waves per SIMD the walkers (and the launch the bounce walk shares with the shadow rays) are compiled for.  Eight: 64
+// registers, nothing spilled; the closest-hit walk then parks six leaves per lane instead of eight, so that its 4.8 KB of
+// LDS per wave fit eight times four into a CU's 160 KB (seven waves with eight parked leaves: 1 % slower with frames in
+// flight, the walk alone 4 %; six waves: another 3 %).
 #ifndef RT_WAVES_PER_SIMD
-#define RT_WAVES_PER_SIMD 7
+#define RT_WAVES_PER_SIMD 8
 #endif
 #ifndef RT_MIN_GROUP_SHIFT
 #define RT_MIN_GROUP_SHIFT 4
@@ -254,7 +255,7 @@ __device__ __forceinline__ void flush_work(unsigned a, unsigned b, unsigned c, W
 #define RT_LEAF_QUEUE 12
 #endif
 #ifndef RT_LEAF_QUEUE_CLOSEST
-#define RT_LEAF_QUEUE_CLOSEST 8
+#define RT_LEAF_QUEUE_CLOSEST 6
 #endif
 constexpr int kLdsStack = RT_LDS_STACK;
 constexpr int kLeafQueue = RT_LEAF_QUEUE;                // parked leaves per lane, any-hit walks
