@@ -520,6 +520,23 @@ def main():
                                        "of the next: shadow_walk_kernel)" % (info.device_bytes / 1e6, in_flight)}
             if traffic is not None:
                 out["roofline"]["traffic_unit"] = "bytes/launch at the L2's memory side, (2*FETCH_SIZE + WRITE_SIZE) KiB, from profiles/" + traffic_src
+            # the same figures for all three groups, so that the runner-up shows as well (on the 1080p bunny the closest-hit walk and
+            # the two shadow launches are within a few per cent of each other, and which one leads differs from box to box)
+            names_all = ("closest_hits", "shadow_rays", "primary_rays_screen_space")
+            keys_all = (closest_key, shadow_key, raster_key)
+            out["roofline_all"] = {}
+            for g in range(3):
+                if group_launches[g] <= 0 or group_ms[g] <= 0:
+                    continue
+                lpf = group_launches[g] / a.steps
+                ms_l = group_ms[g] / group_launches[g]
+                tr, _ = pmc_traffic(name, keys_all[g])
+                gb = byts[g] / lpf / (ms_l * 1e-3) / 1e9
+                tf = flops[g] / lpf / (ms_l * 1e-3) / 1e12
+                out["roofline_all"][names_all[g]] = {"kernel": keys_all[g], "avg_launch_ms": round(ms_l, 4), "launches_per_frame": lpf,
+                                                     "hbm_GBs": round(gb, 1), "hbm_frac": round(gb / PEAK_HBM_GBS, 4),
+                                                     "valu_TFLOPs": round(tf, 3), "valu_frac": round(tf / PEAK_FP32_TFLOPS, 4),
+                                                     "traffic": None if tr is None else round(tr)}
             ach = flops_launch / (per_launch_ms * 1e-3) / 1e12
             out["roofline_valu"] = {"kernel": kname, "bound": "valu", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                                     "frac": round(ach / PEAK_FP32_TFLOPS, 4), "algorithmic_flops_per_launch": round(flops_launch)}
