@@ -1597,6 +1597,9 @@ __global__ __launch_bounds__(256) void raster_kernel(DeviceScene sc, FrameConst 
 #define RT_SHADOW_BATCH 4
 #endif
 static_assert(RT_SHADOW_BATCH >= 1 && RT_SHADOW_BATCH <= 8, "the entry arrays are padded by seven entries (kShadowGridPadding in shadow_grid.hpp)");
+#ifndef RT_SHADOW_SCALAR_HEADERS
+#define RT_SHADOW_SCALAR_HEADERS 1
+#endif
 #ifndef RT_SHADOW_XCD
 #define RT_SHADOW_XCD 1
 #endif
@@ -1638,14 +1641,28 @@ __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const Fr
         const float *hp = ws.hits[depth & 1].p;
         const int hit_c = valid ? hit : 0; // lanes past the end stay in step for the cross-lane vote below
         const V3 o = mk(hp[hit_c], hp[(size_t)ws.capacity + hit_c], hp[2 * (size_t)ws.capacity + hit_c]);
+#if RT_SHADOW_SCALAR_HEADERS
+        // (the sample is the same for the whole wave: its direction and its grid header come through the scalar unit, from
+        // arrays no kernel ever writes, instead of as sixty-four identical vector fetches)
+        typedef const float __attribute__((address_space(4))) *ConstFloats;
+        const ConstFloats sample_dir = (ConstFloats)(sc.samples + 3 * __builtin_amdgcn_readfirstlane(sample));
+        const V3 d = mk(sample_dir[0], sample_dir[1], sample_dir[2]);
+#else
         const V3 d = mk(sc.samples[3 * sample], sc.samples[3 * sample + 1], sc.samples[3 * sample + 2]);
+#endif
         bool blocked = false;
         // intersects(): spheres first (:673-676)
         float tbest = FLT_MAX;
         if (sc.num_spheres > 0 && spheres_hit(sc, o, d, fc.t_eps, tbest)) blocked = true;
         if (!blocked && valid) {
+#if RT_SHADOW_SCALAR_HEADERS
+            const ConstFloats hdr = (ConstFloats)((const float *)sc.grid_headers + 16 * __builtin_amdgcn_readfirstlane(sample));
+            const float4 g0 = make_float4(hdr[0], hdr[1], hdr[2], hdr[3]), g1 = make_float4(hdr[4], hdr[5], hdr[6], hdr[7]);
+            const float4 g2 = make_float4(hdr[8], hdr[9], hdr[10], hdr[11]), g3 = make_float4(hdr[12], hdr[13], hdr[14], hdr[15]);
+#else
             const float4 g0 = sc.grid_headers[sample * 4 + 0], g1 = sc.grid_headers[sample * 4 + 1];
             const float4 g2 = sc.grid_headers[sample * 4 + 2], g3 = sc.grid_headers[sample * 4 + 3];
+#endif
             // header: U (g0.xyz), V (g0.w g1.xy), W (g1.zw g2.x), u0 v0 inv_cell (g2.yzw), res first_cell (g3.xy)
             const float u = o.x * g0.x + (o.y * g0.y + o.z * g0.z);
             const float v = o.x * g0.w + (o.y * g1.x + o.z * g1.y);
