@@ -1762,6 +1762,11 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
     const HitList hl = ws.hits[depth & 1];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool from_keys = PRIMARY && ws.pix_key != nullptr && keys_accepted(ws); // the pass was resolved face by face
+    // (faces too large for the face pass: counted by that pass, constant here -- read once, through the scalar unit, instead of
+    // as a vector fetch with a wait of its own before every use)
+    int nbig_listed = 0;
+    if (PRIMARY && ws.pix_key != nullptr)
+        nbig_listed = __builtin_amdgcn_readfirstlane(*(const int __attribute__((address_space(4))) *)&ws.bin_state->num_big);
     if (PRIMARY && ws.pix_key != nullptr && block == 0 && tid == 0 && ws.bin_feedback) { // the pass's verdict, for the next frames of the view
         ws.bin_feedback[0] = 0, ws.bin_feedback[1] = ws.bin_state->num_big; // [1]: faces too large for the face pass
         ws.bin_feedback[2] = from_keys ? 0 : 1, ws.bin_feedback[3] = 1;
@@ -1770,7 +1775,7 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
     for (int first = block * (256 * kCompactSegments); first < total; first += nblocks * (256 * kCompactSegments)) {
     // A run of tiles none of which the face pass flagged holds no hit, and its pixels already hold the miss values: the
     // workgroup moves on (the same decision in every thread; no LDS was touched, so the barrier below is not needed).
-    if (PRIMARY && from_keys && ws.prefilled && ws.bin_state->num_big == 0 && sc.num_spheres == 0) {
+    if (PRIMARY && from_keys && ws.prefilled && nbig_listed == 0 && sc.num_spheres == 0) {
         int any = 0;
 #pragma unroll
         for (int j = 0; j < kCompactSegments; ++j) {
@@ -1802,7 +1807,7 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
             if (ws.prefilled) { // (only such a pass sets flags)
                 flagged = slot < total ? ws.tile_flag[slot >> 6] : 0;
                 if (flagged && lane == 0) ws.tile_flag[slot >> 6] = 0; // read once per pass, left clean for the next one
-                if (ws.bin_state->num_big != 0 || sc.num_spheres != 0) flagged = 1;
+                if (nbig_listed != 0 || sc.num_spheres != 0) flagged = 1;
             }
             if (valid && flagged) {
                 float tbest = FLT_MAX;
@@ -1815,7 +1820,7 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
                     best_rank = 0x7fffffff - (int)(unsigned)(~held & 0xffffffffull);
                     tri = sc.tri_of_rank[best_rank];
                 }
-                const int nbig = ws.bin_state->num_big;
+                const int nbig = nbig_listed;
                 if (nbig > 0 || sc.num_spheres > 0) {
                     const V3 o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
                     const V3 d = primary_direction(fc, ws, x, row);
