@@ -1683,8 +1683,12 @@ __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const Fr
                     for (int k = 0; k < RT_SHADOW_BATCH; ++k) ent[k] = ep[k];
                     const char *const records = (const char *)sc.tris;
                     float4 pn[RT_SHADOW_BATCH];
+                    // (a lane asks only for the planes it will test: entries past its list's end or behind its origin are masked out)
 #pragma unroll
-                    for (int k = 0; k < RT_SHADOW_BATCH; ++k) pn[k] = *(const float4 *)((const char *)sc.planes + ((unsigned)ent[k].x << 4));
+                    for (int k = 0; k < RT_SHADOW_BATCH; ++k) {
+                        pn[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (e + k < end && !(__int_as_float(ent[k].y) < z)) pn[k] = *(const float4 *)((const char *)sc.planes + ((unsigned)ent[k].x << 4));
+                    }
                     bool behind = false;
 #pragma unroll
                     for (int k = 0; k < RT_SHADOW_BATCH; ++k) {
