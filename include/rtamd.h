@@ -70,10 +70,11 @@ typedef struct {
     int32_t num_faces;
     const rtamd_material *materials;
     int32_t num_materials;
-    const float *light_positions;      /* num_lights*3                                               */
+    const float *light_positions;      /* num_lights*3                  (Flyscene::lights)           */
     const float *light_colors;         /* num_lights*3 (carried; the reference never applies it)     */
     int32_t num_lights;
-    const float *light_samples;        /* num_lights*samples_per_light*3 (PrecomputedData::lights)   */
+    const float *light_samples;        /* (num_lights - num_unsampled_lights)*samples_per_light*3
+                                          (PrecomputedData::lights)                                  */
     int32_t samples_per_light;
     const rtamd_sphere *spheres;
     int32_t num_spheres;
@@ -82,6 +83,11 @@ typedef struct {
     const int32_t *material_textures;  /* num_materials: index into textures, -1 = material has no map_kd */
     const rtamd_texture *textures;
     int32_t num_textures;
+    /* The LAST num_unsampled_lights entries of the light list have no shadow sample points: the state
+     * Flyscene::addLight leaves (src/flyscene.hpp:76 appends to `lights`; precomputeLights ran once, in
+     * initialize, src/flyscene.cpp:117).  shadeOffFace loops over all num_lights (:505), getLightIntensity
+     * over the sampled ones only (:880).  0 = every light is sampled. */
+    int32_t num_unsampled_lights;
 } rtamd_scene_desc;
 
 #define RTAMD_PRIMARY_RAYS_AUTO 0 /* all primary rays share the eye: every face is projected and tested against the pixels of
@@ -205,6 +211,12 @@ void rtamd_render_params_default(rtamd_render_params *p, int32_t width, int32_t 
  * and uploads everything to the current HIP device. */
 int rtamd_scene_create(const rtamd_scene_desc *desc, const rtamd_build_params *build, rtamd_scene **out);
 int rtamd_scene_destroy(rtamd_scene *scene);
+/* Replaces the scene's light list (Flyscene::lights, src/flyscene.hpp:163) and leaves the shadow sample points
+ * (PrecomputedData::lights) as they are: what Flyscene::addLight does to a scene that is already initialised
+ * (src/flyscene.hpp:76).  num_lights must not be smaller than the number of sampled lights the scene was created
+ * with; the lights beyond those are shaded (src/flyscene.cpp:505) but cast no shadow rays (:880).  Waits for the
+ * frames in flight; nothing is rebuilt. */
+int rtamd_scene_set_lights(rtamd_scene *scene, const float *light_positions, const float *light_colors, int32_t num_lights);
 int rtamd_scene_get_info(const rtamd_scene *scene, rtamd_scene_info *info);
 /* Device memory the scene holds beside its own data (rtamd_scene_info::device_bytes): the work buffers of the frames in
  * flight, one set per stream it has been rendered on (hit lists, ray queues, shadow results, per-pixel keys), sized for the

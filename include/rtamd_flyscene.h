@@ -49,8 +49,10 @@ int rtfly_set_build_params(rtfly *f, const rtamd_build_params *b);
  * With upload = 0 the device is not touched (host-side arrays only). */
 int rtfly_initialize(rtfly *f, int32_t width, int32_t height, int32_t upload);
 
-/* Flyscene::addLight, src/flyscene.hpp:76: a white light at the camera centre.  Rebuilds the light
- * samples and re-uploads the scene. */
+/* Flyscene::addLight, src/flyscene.hpp:76: a white light at the camera centre, appended to the light list
+ * and nothing else.  Like the reference -- which computes the shadow sample points once, in initialize
+ * (src/flyscene.cpp:117) -- it gives the new light NO sample points: the light is shaded (:505) but casts no
+ * shadow rays (:880).  Before rtfly_initialize the light simply joins the list and is sampled with the rest. */
 int rtfly_add_light(rtfly *f);
 
 /* Camera (Tucano::Flycamera subset). */

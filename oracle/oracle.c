@@ -71,7 +71,8 @@ struct orc_scene {
     /* S4: PrecomputedData */
     float *P_v, *P_n, *P_D;
     /* S5 */
-    int nl, spl;
+    int nl, spl;   /* lights that have a set of shadow sample points (PrecomputedData::lights), points per set */
+    int nl_shade;  /* entries of Flyscene::lights: nl + the lights addLight pushed after precomputeLights ran */
     float *light_pos, *light_col, *samples;
     /* spheres */
     int ns;
@@ -597,7 +598,7 @@ void orc_scene_precompute(orc_scene *s, int32_t normalize_model) {
 void orc_scene_set_lights(orc_scene *s, const float *pos_color, int32_t nlights, int32_t hard_shadow,
                           int32_t soft_points, float soft_radius) {
     free(s->light_pos), free(s->light_col), free(s->samples);
-    s->nl = nlights;
+    s->nl = s->nl_shade = nlights;
     s->spl = (hard_shadow ? 1 : 0) + soft_points;
     s->light_pos = (float *)calloc((size_t)nlights * 3 + 1, sizeof(float));
     s->light_col = (float *)calloc((size_t)nlights * 3 + 1, sizeof(float));
@@ -622,6 +623,18 @@ void orc_scene_set_lights(orc_scene *s, const float *pos_color, int32_t nlights,
             out[3 * k + 2] = pos_color[6 * i + 2] + z;
         }
     }
+}
+
+/* Flyscene::addLight, flyscene.hpp:76: the light is appended to `lights` only.  precomputeLights runs once, in
+ * initialize (flyscene.cpp:117), so the new light gets no shadow sample points: shadeOffFace's loop (:505) sees it,
+ * getLightIntensity's loop over precomputedData.lights (:880) does not. */
+void orc_scene_add_light(orc_scene *s, const float *pos_color) {
+    const int n = s->nl_shade + 1;
+    s->light_pos = (float *)realloc(s->light_pos, ((size_t)n * 3 + 1) * sizeof(float));
+    s->light_col = (float *)realloc(s->light_col, ((size_t)n * 3 + 1) * sizeof(float));
+    memcpy(s->light_pos + 3 * (size_t)s->nl_shade, pos_color, 12);
+    memcpy(s->light_col + 3 * (size_t)s->nl_shade, pos_color + 3, 12);
+    s->nl_shade = n;
 }
 
 void orc_scene_set_spheres(orc_scene *s, const float *spheres, int32_t n) {
@@ -735,6 +748,7 @@ int32_t orc_num_vertices(const orc_scene *s) { return s->nv; }
 int32_t orc_num_faces(const orc_scene *s) { return s->nf; }
 int32_t orc_num_materials(const orc_scene *s) { return s->nmat; }
 int32_t orc_num_lights(const orc_scene *s) { return s->nl; }
+int32_t orc_num_shading_lights(const orc_scene *s) { return s->nl_shade; }
 int32_t orc_samples_per_light(const orc_scene *s) { return s->spl; }
 const float *orc_raw_vertices(const orc_scene *s) { return s->raw_v; }
 const float *orc_raw_normals(const orc_scene *s) { return s->raw_n; }
@@ -1018,7 +1032,7 @@ static v3 shade_off_face(tctx *c, int face, v3 origin, v3 hit, v3 LI) {
         }
     }
     v3 color = v3_make(0, 0, 0);
-    for (int l = 0; l < s->nl; ++l) {
+    for (int l = 0; l < s->nl_shade; ++l) { /* :505, every entry of `lights` */
         const v3 lp = v3_make(s->light_pos[3 * l], s->light_pos[3 * l + 1], s->light_pos[3 * l + 2]);
         const v3 L = v3_normalized(v3_sub(lp, hit));
         const v3 ambient = v3_mul(LI, ka);
@@ -1071,8 +1085,8 @@ static v3 trace_ray(tctx *c, v3 origin, v3 direction, int depth, hit_t *primary,
     return v3_make(c->prm->background_deep[0], c->prm->background_deep[1], c->prm->background_deep[2]);
 }
 
-/* Camera::screenToWorld + the normalisation in tracePixels, camera.hpp:158-176,271-274; flyscene.cpp:820-822 */
-static v3 screen_ray(const orc_camera *cam, float px, float py) {
+/* Camera::screenToWorld, camera.hpp:158-176,271-274 */
+static v3 screen_point(const orc_camera *cam, float px, float py) {
     const float *vp = cam->viewport;
     v3 n;
     n.x = (float)(2.0 * (double)(px - vp[0]) / (double)vp[2] - 1.0);
@@ -1082,9 +1096,23 @@ static v3 screen_ray(const orc_camera *cam, float px, float py) {
     const float scale = (float)(1.0 / (double)persp);
     n.x *= cam->aspect_ratio * scale;
     n.y *= scale;
-    const v3 world = affine_point(cam->inv_view, n);
+    return affine_point(cam->inv_view, n);
+}
+
+/* ... + the normalisation in tracePixels, flyscene.cpp:820-822 */
+static v3 screen_ray(const orc_camera *cam, float px, float py) {
+    const v3 world = screen_point(cam, px, py);
     const v3 origin = v3_make(cam->origin[0], cam->origin[1], cam->origin[2]);
     return v3_normalized(v3_sub(world, origin));
+}
+
+void orc_screen_points(const orc_camera *cam, int32_t width, int32_t height, int32_t ystep, float *out) {
+    if (ystep < 1) ystep = 1;
+    for (int y = 0; y < height; y += ystep)
+        for (int x = 0; x < width; ++x) {
+            const v3 p = screen_point(cam, (float)x, (float)y);
+            *out++ = p.x, *out++ = p.y, *out++ = p.z;
+        }
 }
 
 void orc_screen_ray(const orc_camera *cam, float px, float py, float *direction) {

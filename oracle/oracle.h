@@ -97,6 +97,10 @@ void orc_scene_precompute(orc_scene *s, int32_t normalize_model);
 /* lights: pos_color = L x 6 floats.  S5: Flyscene::precomputeLights, flyscene.cpp:221-250. */
 void orc_scene_set_lights(orc_scene *s, const float *pos_color, int32_t nlights, int32_t hard_shadow,
                           int32_t soft_points, float soft_radius);
+/* Flyscene::addLight, flyscene.hpp:76: appends one light (pos_color = 6 floats) WITHOUT shadow sample points --
+ * precomputeLights ran once, in initialize (flyscene.cpp:117).  shadeOffFace loops over it (:505),
+ * getLightIntensity (:880) does not. */
+void orc_scene_add_light(orc_scene *s, const float *pos_color);
 /* spheres = n x 4 floats (center, radius), defs.h:22-25. */
 void orc_scene_set_spheres(orc_scene *s, const float *spheres, int32_t n);
 /* B1+B2: boundingVectors (flyscene.cpp:841-868) + boundingBox::splitBox (boundingBox.h:69-194). */
@@ -106,7 +110,8 @@ void orc_scene_build_bvh(orc_scene *s);
 int32_t orc_num_vertices(const orc_scene *s);
 int32_t orc_num_faces(const orc_scene *s);
 int32_t orc_num_materials(const orc_scene *s);
-int32_t orc_num_lights(const orc_scene *s);
+int32_t orc_num_lights(const orc_scene *s);          /* lights with shadow sample points            */
+int32_t orc_num_shading_lights(const orc_scene *s);  /* all lights, those of orc_scene_add_light too */
 int32_t orc_samples_per_light(const orc_scene *s);
 const float *orc_raw_vertices(const orc_scene *s);          /* nv*3, file coordinates           */
 const float *orc_raw_normals(const orc_scene *s);           /* nv*3, before normalisation       */
@@ -143,6 +148,9 @@ int32_t orc_render(orc_scene *s, const orc_camera *cam, const orc_params *p, flo
 int32_t orc_intersects(orc_scene *s, const float *origin, const float *direction, const orc_params *p,
                        int32_t *face_id, float *t_hit, float *hitpoint, float *reflection);
 void orc_screen_ray(const orc_camera *cam, float px, float py, float *direction);
+/* Camera::screenToWorld (camera.hpp:158-176) of every pixel corner (x, y), x in [0, width), y = 0, ystep, 2*ystep, ...
+ * < height: the world point BEFORE tracePixels subtracts the origin and normalises.  out = rows*width*3 floats. */
+void orc_screen_points(const orc_camera *cam, int32_t width, int32_t height, int32_t ystep, float *out);
 
 /* O1: ppmIO.hpp:188-209. */
 int32_t orc_write_ppm(const char *path, const float *rgb, int32_t width, int32_t height);

@@ -85,6 +85,7 @@ def load(fast=False):
     lib.orc_scene_free.argtypes = [P]
     lib.orc_scene_precompute.argtypes = [P, C.c_int32]
     lib.orc_scene_set_lights.argtypes = [P, fp, C.c_int32, C.c_int32, C.c_int32, C.c_float]
+    lib.orc_scene_add_light.argtypes = [P, fp]
     lib.orc_scene_set_spheres.argtypes = [P, fp, C.c_int32]
     lib.orc_scene_build_bvh.argtypes = [P]
     lib.orc_scene_set_texcoords.argtypes = [P, fp]
@@ -99,7 +100,7 @@ def load(fast=False):
     lib.orc_texture_data.argtypes = [P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.orc_material_textures.restype = ip
     lib.orc_material_textures.argtypes = [P]
-    for fn in ("orc_num_vertices", "orc_num_faces", "orc_num_materials", "orc_num_lights", "orc_samples_per_light",
+    for fn in ("orc_num_vertices", "orc_num_faces", "orc_num_materials", "orc_num_lights", "orc_num_shading_lights", "orc_samples_per_light",
                "orc_bvh_node_count", "orc_bvh_leaf_count", "orc_bvh_depth"):
         getattr(lib, fn).restype = C.c_int32
         getattr(lib, fn).argtypes = [P]
@@ -121,6 +122,7 @@ def load(fast=False):
     lib.orc_intersects.restype = C.c_int32
     lib.orc_intersects.argtypes = [P, fp, fp, C.POINTER(Params), ip, fp, fp, fp]
     lib.orc_screen_ray.argtypes = [C.POINTER(Camera), C.c_float, C.c_float, fp]
+    lib.orc_screen_points.argtypes = [C.POINTER(Camera), C.c_int32, C.c_int32, C.c_int32, fp]
     lib.orc_write_ppm.restype = C.c_int32
     lib.orc_write_ppm.argtypes = [C.c_char_p, fp, C.c_int32, C.c_int32]
     _libs[name] = lib
@@ -190,6 +192,11 @@ class OracleScene:
     def set_lights(self, lights, hard_shadow=True, soft_points=12, soft_radius=0.3):
         pc = np.ascontiguousarray(np.array(lights, np.float32).reshape(-1, 6))
         self.lib.orc_scene_set_lights(self.h, _fptr(pc), len(pc), int(hard_shadow), int(soft_points), float(soft_radius))
+
+    def add_light(self, position, color=(1.0, 1.0, 1.0)):
+        """Flyscene::addLight (flyscene.hpp:76): a light without shadow sample points."""
+        pc = np.ascontiguousarray(np.array([*position, *color], np.float32))
+        self.lib.orc_scene_add_light(self.h, _fptr(pc))
 
     def close(self):
         if getattr(self, "h", None):
@@ -309,6 +316,14 @@ def screen_ray(camera, px, py, fast=False):
     d = np.zeros(3, np.float32)
     load(fast).orc_screen_ray(C.byref(camera), float(px), float(py), _fptr(d))
     return d
+
+
+def screen_points(camera, width, height, ystep=1):
+    """Camera::screenToWorld of the pixel corners of every ystep-th row: [rows, width, 3]."""
+    rows = (height + ystep - 1) // ystep
+    out = np.zeros((rows, width, 3), np.float32)
+    load().orc_screen_points(C.byref(camera), width, height, ystep, _fptr(out))
+    return out
 
 
 def write_ppm(path, rgb, fast=False):

@@ -41,6 +41,7 @@ class SceneDesc(C.Structure):
         ("light_samples", _fp), ("samples_per_light", C.c_int32),
         ("spheres", C.POINTER(Sphere)), ("num_spheres", C.c_int32),
         ("face_texcoords", _fp), ("material_textures", _ip), ("textures", C.POINTER(Texture)), ("num_textures", C.c_int32),
+        ("num_unsampled_lights", C.c_int32),
     ]
 
 
@@ -107,6 +108,7 @@ SYMBOLS = {
     "rtamd_render_params_default": (None, [C.POINTER(RenderParams), C.c_int32, C.c_int32]),
     "rtamd_scene_create": (C.c_int, [C.POINTER(SceneDesc), C.POINTER(BuildParams), C.POINTER(_P)]),
     "rtamd_scene_destroy": (C.c_int, [_P]),
+    "rtamd_scene_set_lights": (C.c_int, [_P, _fp, _fp, C.c_int32]),
     "rtamd_scene_get_info": (C.c_int, [_P, C.POINTER(SceneInfo)]),
     "rtamd_scene_workspace_bytes": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "rtamd_scene_set_workspace_limit": (C.c_int, [_P, C.c_uint64]),

@@ -64,9 +64,11 @@ struct TimedLaunch {
 
 constexpr int kMaxFrameSlots = 32;
 constexpr int kMaxHugeFaceList = 192; // kMaxHugeFaces of kernels.hip: entries of the list the compaction kernel tests against every pixel
-// Page-locked report block of a frame slot: [0..3] what the screen binning found, [kStageFeedbackAt + 2 * stage + {0, 1}]
-// hits and spawned rays of every stage, each + 1 (0: not reported yet).
-constexpr int kStageFeedbackAt = 16;
+// Page-locked report block of a frame slot: [4 * band + 0..3] what the screen-space pass of that band of rows found (a frame
+// rendered whole is band 0; a frame has at most kMaxStages bands), [kStageFeedbackAt + 2 * stage + {0, 1}] hits and spawned
+// rays of every stage, each + 1 (0: not reported yet).
+constexpr int kVerdictInts = 4;
+constexpr int kStageFeedbackAt = kVerdictInts * kMaxStages;
 constexpr int kFeedbackInts = kStageFeedbackAt + 2 * kMaxStages;
 
 // What one frame in flight owns.
@@ -87,7 +89,7 @@ struct FrameSlot {
     volatile int32_t *feedback = nullptr;
     uint64_t feedback_key = 0;    // image size and partition the report belongs to
     uint64_t view_key = 0;        // ... and the camera and pass structure the stage counts belong to
-    int frames_without_bins = 0;
+    int frames_without_bins[kMaxStages] = {}; // per band of rows, like the verdicts
 };
 
 } // namespace
@@ -374,11 +376,14 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     if (d->num_faces > 0 && (!d->vertices || !d->normals || !d->face_vertex_ids || !d->face_normals || !d->face_origin_distance || !d->face_material_ids))
         return fail(RTAMD_ERR_INVALID, "null mesh array");
     if (d->num_faces >= (1 << 27)) return fail(RTAMD_ERR_LIMIT, "%d faces exceed the 2^27 limit", d->num_faces);
-    if ((d->num_materials > 0 && !d->materials) || (d->num_lights > 0 && (!d->light_positions || !d->light_samples)) ||
-        (d->num_spheres > 0 && !d->spheres))
+    if (d->num_unsampled_lights < 0 || d->num_unsampled_lights > d->num_lights)
+        return fail(RTAMD_ERR_INVALID, "%d of %d lights without shadow samples", d->num_unsampled_lights, d->num_lights);
+    const int32_t sampled_lights = d->num_lights - d->num_unsampled_lights; // PrecomputedData::lights.size()
+    if ((d->num_materials > 0 && !d->materials) || (d->num_lights > 0 && !d->light_positions) ||
+        (sampled_lights > 0 && d->samples_per_light > 0 && !d->light_samples) || (d->num_spheres > 0 && !d->spheres))
         return fail(RTAMD_ERR_INVALID, "null material, light or sphere array");
-    if ((int64_t)d->num_lights * d->samples_per_light > kMaxShadowRays)
-        return fail(RTAMD_ERR_LIMIT, "%d lights x %d samples exceed %d shadow rays per hit", d->num_lights, d->samples_per_light, kMaxShadowRays);
+    if ((int64_t)sampled_lights * d->samples_per_light > kMaxShadowRays)
+        return fail(RTAMD_ERR_LIMIT, "%d lights x %d samples exceed %d shadow rays per hit", sampled_lights, d->samples_per_light, kMaxShadowRays);
     for (int32_t f = 0; f < d->num_faces; ++f) {
         for (int k = 0; k < 3; ++k) {
             const int32_t id = d->face_vertex_ids[3 * (size_t)f + k];
@@ -455,7 +460,7 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     ShadowGrids grids;
     const bool want_grids = !(build && build->shadow_rays == RTAMD_SHADOW_RAYS_TREE);
     bool grids_on_device = want_grids && builder_used == RTAMD_BUILDER_DEVICE_LBVH;
-    if (want_grids && !grids_on_device) build_shadow_grids(bvh, d->light_samples, d->num_lights * d->samples_per_light, grids);
+    if (want_grids && !grids_on_device) build_shadow_grids(bvh, d->light_samples, sampled_lights * d->samples_per_light, grids);
     const double tg = now_ms();
     // one record per TriRecord, in the same (leaf) order: hits that are neighbours in space read neighbouring records,
     // and the shading kernels need no detour over the face index
@@ -519,7 +524,8 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
             texels.insert(texels.end(), t.rgb, t.rgb + (size_t)t.width * t.height * 3);
         }
     std::vector<float> lpos(d->light_positions, d->light_positions + 3 * (size_t)d->num_lights);
-    std::vector<float> samples(d->light_samples, d->light_samples + 3 * (size_t)d->num_lights * d->samples_per_light);
+    std::vector<float> samples;
+    if (sampled_lights > 0 && d->samples_per_light > 0) samples.assign(d->light_samples, d->light_samples + 3 * (size_t)sampled_lights * d->samples_per_light);
     std::vector<rtamd_sphere> spheres(d->spheres, d->spheres + d->num_spheres);
     if (rc == RTAMD_OK) rc = upload(&s->d_nodes, bvh.nodes4, &bytes);
     if (rc == RTAMD_OK) rc = upload(&s->d_tris, bvh.tris, &bytes);
@@ -561,13 +567,13 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     if (rc == RTAMD_OK && grids_on_device) {
         const double tg0 = now_ms();
         std::string why;
-        if (build_shadow_grids_device(bvh.tris, s->d_tris, d->light_samples, d->num_lights * d->samples_per_light, shadow_grid_density(bvh.tris.size()), dgrids, why)) {
+        if (build_shadow_grids_device(bvh.tris, s->d_tris, d->light_samples, sampled_lights * d->samples_per_light, shadow_grid_density(bvh.tris.size()), dgrids, why)) {
             s->d_grid_cells = dgrids.d_cell_start, s->d_grid_entries = dgrids.d_entries;
             bytes += dgrids.num_cells * 4 + dgrids.num_entries * sizeof(ShadowGridEntry);
             rc = upload(&s->d_grid_headers, dgrids.headers, &bytes);
         } else {
             grids_on_device = false;
-            build_shadow_grids(bvh, d->light_samples, d->num_lights * d->samples_per_light, grids);
+            build_shadow_grids(bvh, d->light_samples, sampled_lights * d->samples_per_light, grids);
         }
         grid_ms = now_ms() - tg0;
         if (verbose) std::fprintf(stderr, "rtamd: shadow grids on the %s: %.1f ms%s%s\n", grids_on_device ? "device" : "host", grid_ms, why.empty() ? "" : " -- ", why.c_str());
@@ -615,7 +621,8 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     s->bin_primary = primary_mode == RTAMD_PRIMARY_RAYS_BINS || (primary_mode == RTAMD_PRIMARY_RAYS_AUTO && faces_off);
     s->bin_always = primary_mode == RTAMD_PRIMARY_RAYS_BINS;
     s->info.shadow_grid_entries = !grids_usable ? 0 : grids_on_device ? dgrids.num_entries : (uint64_t)grids.entries.size() - kShadowGridPadding;
-    s->ds.num_lights = d->num_lights;
+    s->ds.num_lights = sampled_lights;
+    s->ds.num_shade_lights = d->num_lights;
     s->ds.spl = d->samples_per_light;
     s->ds.num_spheres = d->num_spheres;
     s->ds.num_materials = d->num_materials;
@@ -670,6 +677,29 @@ int rtamd_scene_destroy(rtamd_scene *s) {
         (void)hipEventDestroy(t.stop);
     }
     delete s;
+    return RTAMD_OK;
+}
+
+int rtamd_scene_set_lights(rtamd_scene *s, const float *positions, const float *colors, int32_t num_lights) {
+    (void)colors; // carried by the boundary, never applied (src/flyscene.cpp:552 builds minSum and drops it)
+    if (!s) return fail(RTAMD_ERR_INVALID, "null scene");
+    if (num_lights < s->ds.num_lights) return fail(RTAMD_ERR_INVALID, "%d lights given, %d of the scene's lights have shadow samples", num_lights, s->ds.num_lights);
+    if (num_lights > 0 && !positions) return fail(RTAMD_ERR_INVALID, "null light positions");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != s->device) return fail(RTAMD_ERR_INVALID, "scene lives on device %d but device %d is current", s->device, dev);
+    void *fresh = nullptr;
+    const size_t bytes = 3 * sizeof(float) * (size_t)num_lights;
+    HIP_TRY(hipMalloc(&fresh, bytes ? bytes : 64));
+    if (bytes && hipMemcpy(fresh, positions, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(fresh);
+        return fail(RTAMD_ERR_HIP, "upload of %d light positions failed", num_lights);
+    }
+    HIP_TRY(hipDeviceSynchronize()); // frames in flight still read the old list
+    if (s->d_light_pos) (void)hipFree(s->d_light_pos);
+    s->d_light_pos = fresh;
+    s->ds.light_pos = (const float *)fresh;
+    s->ds.num_shade_lights = num_lights;
     return RTAMD_OK;
 }
 
@@ -779,7 +809,7 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
     // Face by face, the pass costs a projection per face and a test per pixel of each face's box; the tree walk costs some
     // twenty-five node visits per pixel.  Past eight faces per rendered pixel the projections alone outweigh the walk.
     static const double faces_per_pixel_raster = getenv("RTAMD_RASTER_FACES_PER_PIXEL") ? atof(getenv("RTAMD_RASTER_FACES_PER_PIXEL")) : 8.0;
-    bool faces_ok = s->face_primary && fs.ws.pix_key != nullptr && p->width < 65536 && p->height < 65536 && p->t_epsilon >= 0.0f &&
+    bool faces_ok = s->face_primary && fs.ws.pix_key != nullptr && p->width < 65536 && p->height < 65536 && p->t_epsilon > 0.0f && // (distances are ordered by their bits: -0.0f must not pass)
                     (double)s->info.num_device_faces <= faces_per_pixel_raster * (double)pixels;
     // What earlier frames on this slot reported (page-locked memory their kernels wrote; a frame still in flight may be
     // half-way through updating it, which is harmless: the figures only pick launch sizes and the cheaper of two
@@ -805,19 +835,22 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
             expect_next[(size_t)i] = fs.feedback[kStageFeedbackAt + 2 * i + 1] - 1;
         }
     }
-    if ((bins_ok || faces_ok) && fs.feedback && !s->bin_always) {
-        if (fs.view_key != view_key) { // another view: what earlier passes reported says nothing about it
-            fs.view_key = view_key;
-            fs.feedback[0] = fs.feedback[1] = fs.feedback[2] = fs.feedback[3] = 0;
-            fs.frames_without_bins = 0;
-        }
-        const bool turned_down = fs.feedback[3] != 0 && fs.feedback[2] != 0; // [2]: the pass's own verdict (bins_accepted)
-        bins_kept_before = fs.feedback[3] != 0 && !turned_down;
-        if (turned_down && fs.frames_without_bins < 63) { // try the bins again every 64th frame: the camera may have moved
+    // Every band of rows keeps a verdict of its own: the faces too large for the face pass are counted per band, so one
+    // band may give way to the tree walk while the next one does not.
+    volatile int32_t *const verdict = fs.feedback ? fs.feedback + kVerdictInts * band : nullptr;
+    if (fs.feedback && band == 0 && fs.view_key != view_key) { // another view: what earlier passes reported says nothing about it
+        fs.view_key = view_key;
+        for (int i = 0; i < kStageFeedbackAt; ++i) fs.feedback[i] = 0;
+        for (int &n : fs.frames_without_bins) n = 0;
+    }
+    if ((bins_ok || faces_ok) && verdict && !s->bin_always) {
+        const bool turned_down = verdict[3] != 0 && verdict[2] != 0; // [2]: the pass's own verdict (bins_accepted)
+        bins_kept_before = verdict[3] != 0 && !turned_down;
+        if (turned_down && fs.frames_without_bins[band] < 63) { // try the bins again every 64th frame: the camera may have moved
             bins_ok = faces_ok = false;
-            ++fs.frames_without_bins;
+            ++fs.frames_without_bins[band];
         } else {
-            fs.frames_without_bins = 0;
+            fs.frames_without_bins[band] = 0;
         }
     }
     // Does the view leave most pixels untouched?  Then the output planes are filled with the miss values in one sweep and
@@ -825,7 +858,7 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
     // face pass must be tested pixel by pixel anyway, that sweep is wasted (1.1 M-face field at 4K: 10 % of the frame).
     // Without a report from an earlier frame of the view the sparse form is assumed.
     bool sparse_view = true;
-    if (fs.feedback && fs.view_key == view_key && fs.feedback[3] != 0 && fs.feedback[1] > 0) sparse_view = false;
+    if (verdict && fs.view_key == view_key && verdict[3] != 0 && verdict[1] > 0) sparse_view = false;
     if (expect_hits[(size_t)stage_base] >= 0 && 2 * (size_t)expect_hits[(size_t)stage_base] >= pixels) sparse_view = false;
     if (bins_ok || faces_ok) {
         const float *m = cam->inv_view;
@@ -859,6 +892,7 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
     }
     fs.ws.dir_y = fs.ws.dir_x + tiles_x * 8;
     Workspace ws_frame = fs.ws; // what the kernels of this frame see
+    if (ws_frame.bin_feedback) ws_frame.bin_feedback += kVerdictInts * band;
     if (!bins_ok) ws_frame.bin_entries = nullptr;
     if (!faces_ok) ws_frame.pix_key = nullptr;
     fs.binned = bins_ok;
@@ -939,8 +973,10 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
                 if (d == 0) {
                     if (faces_ok) launch_primary_faces(count, s->ds, fc, ws_frame, s->info.num_device_faces, stream);
                     if (bins_ok) launch_primary_bins(count, s->ds, fc, ws_frame, s->info.num_device_faces, /*cleared=*/true, stream);
-                    // the tree walk behind them runs only where the pass gives way to it; the same view did not before
-                    if (!ws_frame.bins_expected) launch_walk_closest(true, count, s->ds, fc, ws_frame, stage, 0, -1, stream);
+                    // The tree walk behind them does something only where the pass gives way to it, which the device alone
+                    // knows (the report of an earlier frame is a hint: it may belong to a frame still in flight, or to a view
+                    // that has changed since): it is always launched, with a small grid where the hint says "kept".
+                    launch_walk_closest(true, count, s->ds, fc, ws_frame, stage, 0, -1, stream);
                     launch_compact(true, s->ds, fc, ws_frame, stage, 0, spawn, false, rgb, face_id, t_hit, -1, stream, expect_hits[(size_t)stage]);
                 }
                 const int hits_here = expect_hits[(size_t)stage], rays_next = expect_next[(size_t)stage];

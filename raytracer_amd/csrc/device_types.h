@@ -24,7 +24,8 @@ struct DeviceScene {
     const float4 *spheres;    // center, radius
     const int32_t *tri_of_rank; // record index of the face with a given rank (position in the reference's visiting order), -1 = none
     const float4 *cluster_box;  // per 64 consecutive face records: lower corner, upper corner of their vertices (two float4)
-    int32_t num_lights, spl, num_spheres, num_materials;
+    int32_t num_lights, spl, num_spheres, num_materials; // num_lights: lights WITH shadow sample points (getLightIntensity's loop)
+    int32_t num_shade_lights; // entries of light_pos (shadeOffFace's loop): num_lights + the lights added after the samples were made
     int32_t num_textures; // 0 also when the mesh has no texture coordinates
     // shadow-ray candidate grids (shadow_grid.hpp), one per light sample; use_grids = 0: shadow rays walk the tree
     const float4 *grid_headers;   // 4 x float4 per ShadowGridHeader

@@ -532,14 +532,24 @@ bool write_ppm(const std::string &path, const float *rgb, int width, int height)
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+// Eigen's fixed-size reductions associate a three-term sum as x + (y + z) (redux_novec_unroller); every product of the
+// reference's camera code below goes through one, so the terms are grouped the same way here.
+inline float sum3(float x, float y, float z) { return x + (y + z); }
+
+// Matrix3f::inverse() as Eigen 3.3.7 computes it (Eigen/src/LU/InverseImpl.h, compute_inverse<..., 3>): cofactors, the
+// determinant expanded along the FIRST COLUMN, one reciprocal, every cofactor times that reciprocal.
 void mat3_inverse(const float *m /*row-major 3x4, linear part*/, float *inv /*3x3 row-major*/) {
-    const float a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
-    const float c00 = e * i - f * h, c01 = f * g - d * i, c02 = d * h - e * g;
-    const float det = a * c00 + b * c01 + c * c02;
-    const float r = 1.0f / det;
-    inv[0] = c00 * r, inv[1] = (c * h - b * i) * r, inv[2] = (b * f - c * e) * r;
-    inv[3] = c01 * r, inv[4] = (a * i - c * g) * r, inv[5] = (c * d - a * f) * r;
-    inv[6] = c02 * r, inv[7] = (b * g - a * h) * r, inv[8] = (a * e - b * d) * r;
+    auto at = [&](int r, int c) { return m[4 * r + c]; };
+    auto cofactor = [&](int i, int j) { // cofactor_3x3<i, j>
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        return at(i1, j1) * at(i2, j2) - at(i1, j2) * at(i2, j1);
+    };
+    const float c0 = cofactor(0, 0), c1 = cofactor(1, 0), c2 = cofactor(2, 0);
+    const float det = sum3(c0 * at(0, 0), c1 * at(1, 0), c2 * at(2, 0));
+    const float invdet = 1.0f / det;
+    inv[0] = c0 * invdet, inv[1] = c1 * invdet, inv[2] = c2 * invdet;
+    for (int r = 1; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) inv[3 * r + c] = cofactor(c, r) * invdet;
 }
 
 // rotation by `angle` about unit axis `ax` (Rodrigues, as Eigen::AngleAxisf::toRotationMatrix)
@@ -551,7 +561,7 @@ void axis_angle(const float *ax, float angle, float *R) {
     R[6] = t * x * z - s * y, R[7] = t * y * z + s * x, R[8] = t * z * z + c;
 }
 void mul3(const float *R, const float *v, float *o) {
-    for (int r = 0; r < 3; ++r) o[r] = R[3 * r] * v[0] + R[3 * r + 1] * v[1] + R[3 * r + 2] * v[2];
+    for (int r = 0; r < 3; ++r) o[r] = sum3(R[3 * r] * v[0], R[3 * r + 1] * v[1], R[3 * r + 2] * v[2]);
 }
 void norm3(float *v) {
     const float z = v[0] * v[0] + (v[1] * v[1] + v[2] * v[2]);
@@ -609,10 +619,15 @@ void Flycamera::updateViewMatrix() {
     mul3(X, uy, rotY);
     norm3(rotY);
     const float R[9] = {rotX[0], rotX[1], rotX[2], rotY[0], rotY[1], rotY[2], rotZ[0], rotZ[1], rotZ[2]};
-    const float t[3] = {0.0f + translation_[0], 0.0f + translation_[1], -2.0f + translation_[2]};
+    // Affine3f::translate(v) adds linear * v to the translation: once for the default translation (0, 0, -2), once for
+    // the user's (utils/flycamera.hpp:189-190) -- two roundings, not one product with the summed vector
+    const float d[3] = {0.0f, 0.0f, -2.0f};
+    float Ld[3], Lt[3];
+    mul3(R, d, Ld);
+    mul3(R, translation_, Lt);
     for (int r = 0; r < 3; ++r) {
         for (int k = 0; k < 3; ++k) view_[4 * r + k] = R[3 * r + k];
-        view_[4 * r + 3] = R[3 * r] * t[0] + R[3 * r + 1] * t[1] + R[3 * r + 2] * t[2];
+        view_[4 * r + 3] = (0.0f + Ld[r]) + Lt[r];
     }
 }
 
@@ -621,8 +636,8 @@ void Flycamera::reComputeViewMatrix() {
     mat3_inverse(view_, inv);
     for (int r = 0; r < 3; ++r) {
         for (int k = 0; k < 3; ++k) inv_view_[4 * r + k] = inv[3 * r + k];
-        // -(L^-1 * t)
-        inv_view_[4 * r + 3] = -(inv[3 * r] * view_[3] + inv[3 * r + 1] * view_[7] + inv[3 * r + 2] * view_[11]);
+        // -(L^-1 * t), Transform::inverse (Eigen/src/Geometry/Transform.h)
+        inv_view_[4 * r + 3] = -sum3(inv[3 * r] * view_[3], inv[3 * r + 1] * view_[7], inv[3 * r + 2] * view_[11]);
     }
 }
 
@@ -630,7 +645,7 @@ std::array<float, 3> Flycamera::getCenter() const {
     float inv[9];
     mat3_inverse(view_, inv);
     std::array<float, 3> c;
-    for (int r = 0; r < 3; ++r) c[r] = inv[3 * r] * -view_[3] + inv[3 * r + 1] * -view_[7] + inv[3 * r + 2] * -view_[11];
+    for (int r = 0; r < 3; ++r) c[r] = sum3(inv[3 * r] * -view_[3], inv[3 * r + 1] * -view_[7], inv[3 * r + 2] * -view_[11]); // camera.hpp:120
     return c;
 }
 
@@ -704,6 +719,7 @@ void Flyscene::precomputeData() {
 void Flyscene::precomputeLights() {
     const int spl = (hard_shadow ? 1 : 0) + soft_points;
     light_samples.assign(3 * lights.size() * (size_t)spl, 0.0f);
+    sampled_lights = lights.size();
     for (size_t i = 0; i < lights.size(); ++i) {
         float *out = &light_samples[3 * i * (size_t)spl];
         const float *lp = lights[i].position;
@@ -748,6 +764,7 @@ int Flyscene::upload() {
     d.light_positions = lpos.data();
     d.light_colors = lcol.data();
     d.num_lights = (int32_t)lights.size();
+    d.num_unsampled_lights = (int32_t)(lights.size() - std::min(sampled_lights, lights.size())); // lights of addLight()
     d.light_samples = light_samples.data();
     d.samples_per_light = (hard_shadow ? 1 : 0) + soft_points;
     d.spheres = spheres.data();
@@ -784,12 +801,20 @@ int Flyscene::initialize(int width, int height, bool do_upload) {
     return do_upload ? upload() : RTAMD_OK;
 }
 
+// src/flyscene.hpp:76: `lights.push_back(...)` and nothing else.  precomputeLights is NOT run again (the reference
+// calls it once, from initialize, src/flyscene.cpp:117), so the new light has no shadow sample points: it is shaded
+// (:505) but getLightIntensity (:880) never asks whether it is occluded.  The uploaded scene keeps its hierarchy and
+// shadow-ray structures; only its light list is replaced.
 int Flyscene::addLight() {
     const std::array<float, 3> c = flycamera.getCenter();
     lights.push_back(Light{{c[0], c[1], c[2]}, {1.0f, 1.0f, 1.0f}});
-    if (!initialized_) return RTAMD_OK;
-    precomputeLights();
-    return scene_ ? upload() : RTAMD_OK;
+    if (!initialized_ || !scene_) return RTAMD_OK;
+    std::vector<float> lpos, lcol;
+    for (const Light &l : lights) {
+        lpos.insert(lpos.end(), l.position, l.position + 3);
+        lcol.insert(lcol.end(), l.color, l.color + 3);
+    }
+    return rtamd_scene_set_lights(scene_, lpos.data(), lcol.data(), (int32_t)lights.size());
 }
 
 int Flyscene::render(float *rgb, int32_t *face_id, rtamd_stats *stats) {

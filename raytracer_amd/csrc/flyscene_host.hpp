@@ -113,7 +113,8 @@ public:
 
     // --- struct PrecomputedData, src/defs.h:7-20
     std::vector<float> P_vertices, P_normals, P_face_distance;
-    std::vector<float> light_samples;
+    std::vector<float> light_samples; // PrecomputedData::lights: sample points of the first sampled_lights entries of `lights`
+    size_t sampled_lights = 0;        // lights.size() when precomputeLights last ran (the reference runs it once, src/flyscene.cpp:117)
     float model_matrix[12];
     std::vector<rtamd_material> plain_materials;
 

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
     // stack, the lanes prune against the nearest hit any of them has found so far, and their results are merged
     // under the reference's tie rule.  (Sixteen lanes shorten a lone frame's chain as well, 0.179 vs 0.166 ms for
     // 152 K rays, but cost a tenth of the throughput once frames overlap: every lane pays a wave's fixed fetches.)
-    const bool split = MODE == kQueue && alone && rays < kSplitRaysBelow;
+    const bool split = MODE == kQueue && alone && rays < kSplitRaysBelow && fc.t_eps > 0.0f; // (shared distances are ordered by their bits)
     constexpr int kRayLanesShift = RT_SPLIT_LANES_SHIFT, kRayLanes = 1 << kRayLanesShift; // lanes that share one ray
     __shared__ int s_cut[64 >> kRayLanesShift]; // per ray of the wave: bits of the nearest accepted distance
     if (split) shift = 6 - kRayLanesShift;
@@ -1997,9 +1997,9 @@ __device__ __forceinline__ void shade_body(const DeviceScene &sc, const FrameCon
     // the lights' positions once per workgroup (read per hit from global memory they are a fetch per light, one after the other)
     constexpr int kLdsLights = 64;
     __shared__ float s_light[3 * kLdsLights];
-    const bool lights_in_lds = sc.num_lights <= kLdsLights;
+    const bool lights_in_lds = sc.num_shade_lights <= kLdsLights;
     if (lights_in_lds) {
-        for (int i = (int)threadIdx.x; i < 3 * sc.num_lights; i += 256) s_light[i] = sc.light_pos[i];
+        for (int i = (int)threadIdx.x; i < 3 * sc.num_shade_lights; i += 256) s_light[i] = sc.light_pos[i];
         __syncthreads();
     }
     for (int idx = block * 256 + (int)threadIdx.x; idx < nhits; idx += nblocks * 256) {
@@ -2107,7 +2107,7 @@ __device__ __forceinline__ void shade_body(const DeviceScene &sc, const FrameCon
                 albedo = mk(tx[0], tx[1], tx[2]);
             }
             local = mk(0.0f, 0.0f, 0.0f);
-            for (int l = 0; l < sc.num_lights; ++l) {
+            for (int l = 0; l < sc.num_shade_lights; ++l) { // every entry of `lights` (:505), sampled or not
                 const V3 lp = lights_in_lds ? mk(s_light[3 * l], s_light[3 * l + 1], s_light[3 * l + 2])
                                             : mk(sc.light_pos[3 * l], sc.light_pos[3 * l + 1], sc.light_pos[3 * l + 2]);
                 const V3 L = normalized(lp - P);                          // :507
@@ -2353,7 +2353,7 @@ void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const 
         groups = std::min(groups, (with_margin(expect) + (ws.full_waves ? 63 : 15)) / (ws.full_waves ? 64 : 16));
     const int blocks = primary && (ws.bin_entries || ws.pix_key) ? (ws.bins_expected ? 2048 : 16384) : walk_grid(groups);
     static const int steal = getenv("RTAMD_WALK_STEAL") ? atoi(getenv("RTAMD_WALK_STEAL")) : 1; // experiment hook
-    if (steal && fc.t_eps >= 0.0f) { // (the shared nearest distance is ordered by its bits: distances must be positive)
+    if (steal && fc.t_eps > 0.0f) { // (the shared nearest distance is ordered by its bits: distances must be positive, -0.0f included)
         if (primary) {
             if (count)
                 walk_steal_kernel<kPrimary, true><<<blocks, 64, 0, stream>>>(sc, fc, ws, stage, depth, total_static);
@@ -2462,7 +2462,7 @@ int shadow_blocks(const DeviceScene &sc, const FrameConst &fc, int expect) {
 }
 } // namespace
 
-bool can_fuse_shadow_walk(const DeviceScene &sc, const FrameConst &fc) { return sc.use_grids && sc.num_lights * sc.spl > 0 && fc.t_eps >= 0.0f; }
+bool can_fuse_shadow_walk(const DeviceScene &sc, const FrameConst &fc) { return sc.use_grids && sc.num_lights * sc.spl > 0 && fc.t_eps > 0.0f; }
 bool can_fuse_shade_compact(const Workspace &ws) { return ws.capacity <= (4 << 20); }
 
 void launch_shadow_walk(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, int expect_hits,

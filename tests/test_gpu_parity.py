@@ -82,8 +82,8 @@ def test_texture_branch_from_arrays_matches_obj_path_and_oracle():
 
 
 def test_single_stream_flag_and_many_live_scenes():
-    """Frames with reflections use two process-wide side streams; several reflective scenes alive at once must
-    not add streams (hardware queues are few), and RTAMD_FLAG_SINGLE_STREAM must give the same image."""
+    """Every frame runs on its caller's stream alone (the library owns no streams), so several reflective scenes alive
+    at once add none, and RTAMD_FLAG_SINGLE_STREAM, kept for callers that set it, gives the same image."""
     flies = [make_pair("reflect_test", width=64, height=64)[0] for _ in range(4)]
     frames = [f.render()["rgb"] for f in flies]
     for fr in frames[1:]:
@@ -244,6 +244,86 @@ def test_automatic_choice_between_screen_space_and_tree():
     large = R.Flyscene(model=scene_path("bunny"), output="", primary_rays=L.PRIMARY_RAYS_BINS).initialize(1600, 1200)
     st = [large.render(face_ids=False)["stats"] for _ in range(2)][-1]
     assert st.primary_path == 1 and 0 < st.bin_entries <= 38 * st.bins_nonempty
+
+
+def test_view_change_with_frames_in_flight_and_bands_with_different_verdicts():
+    """Whether the screen-space pass of the primary rays stands or gives way to the tree walk is decided on the device, per
+    pass and per band of rows; what earlier frames reported is only a hint for launch sizes.  (1) Frames of a view the pass
+    accepts are still in flight when frames of a view it turns down (eye inside the mesh) are enqueued behind them: the
+    stale report must not cost the second view its walk.  (2) The same view in bands of rows, of which some accept and
+    some give way, frame after frame."""
+    import torch
+
+    W, H = 160, 120
+    auto = R.Flyscene(model=scene_path("toy"), output="").initialize(W, H)
+    walk = R.Flyscene(model=scene_path("toy"), output="", primary_rays=L.PRIMARY_RAYS_TREE).initialize(W, H)
+    outside = walk.render()
+    out_cam = auto.getCamera()
+    for f in (auto, walk):
+        f.camera_translate(0.0, 0.0, 38.0)
+        f.camera_rotate(0.3, -0.7)
+    inside = walk.render()
+    in_cam = auto.getCamera()
+    assert not np.array_equal(outside["face_id"], inside["face_id"])
+    stream = torch.cuda.Stream()
+    for trial in range(3):
+        bufs = []
+        for k in range(10):  # five frames of the outside view, then five of the inside view, no wait in between
+            rgb = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+            fid = torch.full((H, W), -7, dtype=torch.int32, device="cuda")
+            auto.render_device(rgb, fid, camera=out_cam if k < 5 else in_cam, stream=stream)
+            bufs.append((rgb, fid))
+        torch.cuda.synchronize()
+        for k, (rgb, fid) in enumerate(bufs):
+            ref = outside if k < 5 else inside
+            assert np.array_equal(fid.cpu().numpy(), ref["face_id"]), (trial, k)
+            assert np.array_equal(rgb.cpu().numpy().view(np.uint32), ref["rgb"].view(np.uint32)), (trial, k)
+    # bands: the faces that reach round the eye are counted per band
+    banded = R.Flyscene(model=scene_path("toy"), output="").initialize(W, H)
+    banded.camera_translate(0.0, 0.0, 38.0)
+    banded.camera_rotate(0.3, -0.7)
+    banded.render()
+    banded.set_workspace_limit(banded.workspace_bytes() // 6)
+    for again in range(4):
+        got = banded.render()
+        assert np.array_equal(got["face_id"], inside["face_id"]), again
+        assert np.array_equal(got["rgb"].view(np.uint32), inside["rgb"].view(np.uint32)), again
+
+
+def test_add_light_after_initialize_is_shaded_but_casts_no_shadow_rays():
+    """Flyscene::addLight (flyscene.hpp:76) only appends to `lights`; the shadow sample points were made once, in
+    initialize (flyscene.cpp:117).  The new light takes part in shadeOffFace's loop (:505) and not in getLightIntensity's
+    (:880): L + 1 shading lights, L sampled ones."""
+    from oracle.oracle_py import OracleScene
+
+    for name, depth in (("toy_on_plane", 0), ("reflect_test", 3)):
+        fly, orc = make_pair(name, width=96, height=96)
+        before = fly.render()
+        fly.camera_translate(6.0, -4.0, 9.0)
+        fly.addLight()
+        centre = tuple(fly.getCamera().origin)
+        orc.add_light(centre)
+        r = compare(fly, orc, 96, 96, max_reflections=depth)
+        assert_parity(r)
+        st = r["got"]["stats"]
+        assert st.rays_shadow == st.hits * 13  # still the thirteen sample points of the first light
+        assert fly.arrays()["light_samples"].shape == (13, 3)
+        fly.camera_reset()
+        after = fly.render()
+        assert np.abs(after["rgb"] - before["rgb"]).max() > 0.05  # the light is there ...
+        # ... and a scene whose second light WAS sampled looks different: that one casts shadow rays
+        both = R.Flyscene(model=scene_path(name), output="", lights=[(-1.0, 1.0, 1.0), centre]).initialize(96, 96)
+        both.set_params(max_reflections=depth)
+        sb = both.render()["stats"]
+        assert sb.rays_shadow == sb.hits * 26 and sb.hits > 0
+    # no light at initialize: getLightIntensity sums over nothing, the light of addLight shades with intensity zero
+    fly = R.Flyscene(model=scene_path("NthTest"), output="", lights=[]).initialize(64, 64)
+    orc = OracleScene(scene_path("NthTest"), lights=[])
+    fly.addLight()
+    orc.add_light(tuple(fly.getCamera().origin))
+    r = compare(fly, orc, 64, 64)
+    assert_parity(r)
+    assert r["got"]["stats"].rays_shadow == 0 and (r["got"]["face_id"] >= 0).any()
 
 
 @pytest.mark.parametrize("name", ["NthTest", "toy_on_plane", "bunny", "reflect_test", "textured_quad", "glass"])

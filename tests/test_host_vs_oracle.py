@@ -128,3 +128,26 @@ def test_camera_mirror():
     fly.camera_translate(0.0, 0.0, 4.0)  # dz * speed(0.05) towards the scene
     cam = fly.getCamera()
     assert np.allclose(list(cam.origin), [0.0, 0.0, 1.8], atol=1e-6)
+
+
+def test_add_light_appends_to_the_list_and_leaves_the_samples_alone():
+    """Flyscene::addLight (flyscene.hpp:76) is `lights.push_back(getCenter())`; precomputeLights ran once, in initialize
+    (flyscene.cpp:117).  Host: the sample sets stay those of initialize.  Oracle: the extra light changes the shading
+    (shadeOffFace loops over `lights`, :505) but not the shadow rays (getLightIntensity loops over the sample sets, :880)."""
+    fly = R.Flyscene(model=scene_path("glass"), output="").initialize(8, 8, upload=False)
+    before = fly.arrays()["light_samples"].copy()
+    fly.camera_translate(3.0, 1.0, 5.0)
+    fly.addLight()
+    fly.addLight()
+    assert same_bits(fly.arrays()["light_samples"], before) and before.shape == (13, 3)
+    orc = OracleScene(scene_path("glass"))
+    plain = orc.render(48, 48)
+    orc.add_light(tuple(fly.getCamera().origin))
+    lit = orc.render(48, 48)
+    assert orc.lib.orc_num_lights(orc.h) == 1 and orc.lib.orc_num_shading_lights(orc.h) == 2
+    assert lit["counters"].rays_shadow == plain["counters"].rays_shadow and np.array_equal(lit["light"], plain["light"])
+    hit = plain["face_id"] >= 0
+    assert (lit["rgb"][hit] >= plain["rgb"][hit]).all() and (lit["rgb"][hit] > plain["rgb"][hit] + 0.01).any()
+    # a light that IS sampled casts shadow rays of its own
+    two = OracleScene(scene_path("glass"), lights=[(-1, 1, 1, 1, 1, 1), (*fly.getCamera().origin, 1, 1, 1)]).render(48, 48)
+    assert two["counters"].rays_shadow == 2 * plain["counters"].rays_shadow
