@@ -155,8 +155,9 @@ int upload(void **dst, const std::vector<T> &src, uint64_t *bytes) {
 // one hit list, one with a single bounce one queue; three queues and both lists rotate from two bounces on.
 size_t layout_workspace(char *base, size_t slots, size_t nshadow, size_t bins, size_t ntris, bool keys, int depths, Workspace &ws) {
     const size_t cap = (slots + 255) & ~(size_t)255; // every plane starts 1 KiB aligned
-    const size_t head = 4096;                        // stage counters + work counters
+    const size_t head = kCounterHeadBytes;           // stage counters + work counters + shadow-ray counters
     static_assert(sizeof(StageCounters) * kMaxStages <= 2048, "counter block too small");
+    static_assert(2048 + 3 * sizeof(WorkCounters) <= 4096 && 4096 + kShotSlots * kShotStride * 8 <= kCounterHeadBytes, "counter block too small");
     const size_t bin_capacity = bins ? std::min<size_t>(8 * ntris + (1u << 20), (size_t)1 << 30) : 0;
     uintptr_t p = (uintptr_t)base + head;
     auto take = [&](size_t bytes) {
@@ -167,6 +168,7 @@ size_t layout_workspace(char *base, size_t slots, size_t nshadow, size_t bins, s
     auto align = [&](uintptr_t to) { p = (p + to - 1) & ~(to - 1); };
     ws.stage = (StageCounters *)(uintptr_t)base;
     ws.work = (WorkCounters *)((uintptr_t)base + 2048);
+    ws.shadow_shot = (unsigned long long *)((uintptr_t)base + 4096);
     ws.bin_state = nullptr, ws.bin_count = nullptr, ws.bin_start = nullptr, ws.bin_entries = nullptr, ws.big = nullptr;
     ws.pix_key = nullptr, ws.tile_flag = nullptr;
     ws.prefilled = 0;
@@ -421,10 +423,10 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     rtamd_scene *s = new (std::nothrow) rtamd_scene();
     if (!s) return fail(RTAMD_ERR_INVALID, "out of host memory");
     s->device = dev;
-    if (scratch_pointer(dev, &s->scratch) != RTAMD_OK) {
-        delete s;
-        return RTAMD_ERR_HIP;
-    }
+    // (the array of rtamd_render_device_noalloc: looked up here, once per device, so that the entry point itself has
+    // nothing left to set up; a scene that never uses that entry point does not depend on the lookup, and a failure is
+    // reported by the entry point, which tries again)
+    if (scratch_pointer(dev, &s->scratch) != RTAMD_OK) s->scratch = nullptr;
     s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
     // ---- host build
@@ -959,9 +961,9 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
             // a pass that ADDS to the planes (SSAA passes after the first) keeps the pixel-by-pixel form.
             ws_frame.prefilled = faces_ok && !fc.accumulate && sparse_view;
             if (stage == 0) // (the first pass of the first band)
-                launch_prep(fc, ws_frame, fs.block, 4096 + bin_clear, ws_frame.pix_key, key_clear, rgb, face_id, t_hit, stream);
+                launch_prep(fc, ws_frame, fs.block, kCounterHeadBytes + bin_clear, ws_frame.pix_key, key_clear, rgb, face_id, t_hit, stream);
             else
-                launch_prep(fc, ws_frame, (char *)fs.block + 4096, bin_clear, ws_frame.pix_key, key_clear, rgb, face_id, t_hit, stream);
+                launch_prep(fc, ws_frame, (char *)fs.block + kCounterHeadBytes, bin_clear, ws_frame.pix_key, key_clear, rgb, face_id, t_hit, stream);
             // Fused form: the shadow rays of level d share a launch with the closest hits of level d + 1, and the shading of
             // level d with the compaction of level d + 1 (each pair needs only what the launch before it produced), all on
             // the caller's stream.  The GPU runs only a few kernels at a time however many streams feed it, so what a frame
@@ -1165,12 +1167,14 @@ int rtamd_render_stats(rtamd_scene *s, rtamd_stats *st) {
     HIP_TRY(hipMemcpy(sc.data(), ws_last.stage, sizeof(StageCounters) * kMaxStages, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(wc, ws_last.work, sizeof wc, hipMemcpyDeviceToHost));
     st->rays_primary = s->last_primary;
-    const uint64_t per_hit = (uint64_t)s->ds.num_lights * (uint64_t)s->ds.spl;
     for (int i = 0; i < s->last_stages; ++i) {
         st->hits += (uint64_t)sc[i].hits;
-        st->rays_shadow += (uint64_t)sc[i].hits * per_hit;
         st->rays_bounce += (uint64_t)sc[i].next;
     }
+    // shadow rays: what the shadow-ray kernels counted while they shot them (not hits x lights x samples)
+    unsigned long long shot[kShotSlots * kShotStride];
+    HIP_TRY(hipMemcpy(shot, ws_last.shadow_shot, sizeof shot, hipMemcpyDeviceToHost));
+    for (int i = 0; i < kShotSlots; ++i) st->rays_shadow += shot[i * kShotStride];
     for (int k = 0; k < 3; ++k) {
         st->box_tests[k] = wc[k].box_tests;
         st->tri_plane[k] = wc[k].tri_plane;

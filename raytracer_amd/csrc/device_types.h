@@ -93,6 +93,13 @@ struct WorkCounters {
     unsigned long long box_tests, tri_plane, tri_edge, pad;
 };
 
+// Shadow rays actually shot in a frame: every wave of a shadow-ray kernel adds the rays it processed, once, to one of
+// kShotSlots counters, each on a 64-byte line of its own (one counter would take tens of thousands of atomics on one
+// address per launch, which serialise); the host adds the slots up.
+constexpr int kShotSlots = 64;
+constexpr int kShotStride = 8; // 64-bit words between two slots
+constexpr int kCounterHeadBytes = 8192; // stage counters, work counters, shot counters: zeroed at the start of a frame
+
 // Hit list of one stage: positions 0..hits-1, written by the compaction kernel.  Two lists alternate by
 // recursion depth so that the lighting of depth d can run while depth d+1 is traced.
 struct HitList {
@@ -118,6 +125,7 @@ struct Workspace {
     float *dir_x, *dir_y;
     StageCounters *stage; // kMaxStages
     WorkCounters *work;   // [0] closest-hit walk, [1] shadow kernel, [2] screen-bin raster
+    unsigned long long *shadow_shot; // kShotSlots counters, kShotStride words apart: shadow rays shot so far in this frame
     // Primary rays resolved face by face (face_raster_kernel): per pixel of the local image, the complement of (distance
     // bits, inverted rank) of the best face so far, zero = none; nullptr: not in use for this frame
     unsigned long long *pix_key;

@@ -350,6 +350,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
     const int per_sample = MODE == kShadow ? (nhits + width - 1) >> shift : 0; // hit chunks
     const int ngroups = MODE == kShadow ? per_sample * nshadow : (rays + (1 << shift) - 1) >> shift;
     unsigned w_box = 0, w_plane = 0, w_edge = 0;
+    unsigned shot = 0; // shadow rays this wave has shot
 
     for (int group = (int)blockIdx.x; group < ngroups; group += (int)gridDim.x) {
         const int item = split ? (group << (6 - kRayLanesShift)) + (lane >> kRayLanesShift) : (group << shift) + lane;
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
                 d = mk(sc.samples[3 * sample], sc.samples[3 * sample + 1], sc.samples[3 * sample + 2]);
             }
         }
+        if (MODE == kShadow) shot += (unsigned)__popcll(__ballot(valid));
         if (!valid) {
             if (MODE == kPrimary) ws.slot_tri[item] = -2; // padding of an edge tile
             continue;
@@ -587,6 +589,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
             ws.slot_t[out_index] = tbest;
         }
     }
+    if (MODE == kShadow && lane == 0 && shot != 0) atomicAdd(ws.shadow_shot + ((int)blockIdx.x & (kShotSlots - 1)) * kShotStride, (unsigned long long)shot);
     if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + (MODE == kShadow ? 1 : 0));
 }
 
@@ -1618,6 +1621,7 @@ __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const Fr
     const int chunks = (nhits + (1 << per_wave_shift) - 1) >> per_wave_shift;
     const int ngroups = chunks * nshadow;
     unsigned w_box = 0, w_plane = 0, w_edge = 0;
+    unsigned shot = 0; // shadow rays this wave has shot
     // Workgroups b and b + 8 run on the same XCD and share its 4 MiB L2.  Dealt out in launch order, every XCD would see
     // every eighth group of every sample, fetch the lines that neighbouring groups share once per XCD, and stream all
     // grids past its L2.  Instead the XCD class of a workgroup (b & 7) takes runs of consecutive groups of the
@@ -1638,6 +1642,7 @@ __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const Fr
         const int sample = group / chunks, chunk = group - sample * chunks;
         const int hit = (chunk << per_wave_shift) + (lane >> split_shift);
         const bool valid = hit < nhits;
+        shot += (unsigned)__popcll(__ballot(valid && sub == 0)); // (sixteen lanes may share a ray: it counts once)
         const float *hp = ws.hits[depth & 1].p;
         const int hit_c = valid ? hit : 0; // lanes past the end stay in step for the cross-lane vote below
         const V3 o = mk(hp[hit_c], hp[(size_t)ws.capacity + hit_c], hp[2 * (size_t)ws.capacity + hit_c]);
@@ -1726,6 +1731,7 @@ __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const Fr
         for (int m = 1; m < split; m <<= 1) any |= __shfl_xor(any, m, 64);
         if (valid && sub == 0) ws.clear[depth & 1][sample * ws.capacity + hit] = any ? 0 : 1;
     }
+    if (lane == 0 && shot != 0) atomicAdd(ws.shadow_shot + (block & (kShotSlots - 1)) * kShotStride, (unsigned long long)shot);
     if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 1);
 }
 

@@ -69,3 +69,56 @@ def test_noalloc_entry_point_refuses_frames_beyond_its_array():
     assert e.value.code == L.ERR_LIMIT and "rtamd_render_device_noalloc holds" in str(e.value)
     # the scene is still usable afterwards
     same(planes(fly, 64, 64, noalloc=True), planes(fly, 64, 64, noalloc=False))
+
+
+def test_noalloc_entry_point_allocates_nothing_and_can_be_captured_in_a_graph():
+    """The property the entry point exists for.  On a warmed scene the free device memory is the same before and after a
+    run of calls, a scene rendered through this entry point alone owns no work buffers, and a call can be enqueued under
+    stream capture -- where an allocation, an event or a synchronisation would abort the capture -- and replayed to the
+    same bits."""
+    dev = torch.device("cuda", 0)
+    W, H = 200, 120
+    fly = R.Flyscene(model=scene_path("reflect_test"), output="").initialize(W, H)
+    ref = R.Flyscene(model=scene_path("reflect_test"), output="").initialize(W, H)
+    want = planes(ref, W, H, noalloc=False)
+    p = fly.params_copy(width=W, height=H)
+    cam = R.flyscene.default_camera(W, H)
+    rgb = torch.full((H, W, 3), -7.0, dtype=torch.float32, device=dev)
+    fid = torch.full((H, W), -9, dtype=torch.int32, device=dev)
+    t = torch.full((H, W), -7.0, dtype=torch.float32, device=dev)
+    fly.render_device(rgb, fid, t, params=p, camera=cam, noalloc=True)  # warm-up: code objects, the per-device array
+    torch.cuda.synchronize(dev)
+    free_before = torch.cuda.mem_get_info(dev)[0]
+    for _ in range(5):
+        fly.render_device(rgb, fid, t, params=p, camera=cam, noalloc=True)
+    torch.cuda.synchronize(dev)
+    assert torch.cuda.mem_get_info(dev)[0] == free_before
+    assert fly.workspace_bytes() == 0
+    assert np.array_equal(rgb.cpu().numpy().view(np.uint32), want[0].view(np.uint32))
+
+    side = torch.cuda.Stream(dev)
+    graph = torch.cuda.CUDAGraph()
+    rgb.fill_(-7.0), fid.fill_(-9), t.fill_(-7.0)
+    torch.cuda.synchronize(dev)
+    with torch.cuda.graph(graph, stream=side):
+        fly.render_device(rgb, fid, t, params=p, camera=cam, stream=torch.cuda.current_stream(dev), noalloc=True)
+    torch.cuda.synchronize(dev)
+    assert float(rgb.max()) == -7.0  # captured, not run
+    for _ in range(2):
+        rgb.fill_(-7.0), fid.fill_(-9), t.fill_(-7.0)
+        graph.replay()
+        torch.cuda.synchronize(dev)
+        assert np.array_equal(rgb.cpu().numpy().view(np.uint32), want[0].view(np.uint32))
+        assert np.array_equal(fid.cpu().numpy(), want[1])
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), want[2].view(np.uint32))
+
+
+def test_two_scenes_take_turns_in_the_shared_array():
+    """Every scene on a GPU lays its work buffers out in the same static array: frames of different scenes, one after the
+    other, must not see each other's leftovers (keys of the screen-space pass, counters, queues)."""
+    a = R.Flyscene(model=scene_path("toy"), output="").initialize(160, 120)
+    b = R.Flyscene(model=scene_path("reflect_test"), output="").initialize(160, 120)
+    want_a, want_b = planes(a, 160, 120, noalloc=False), planes(b, 144, 81, noalloc=False)
+    for _ in range(2):
+        same(planes(a, 160, 120, noalloc=True), want_a)
+        same(planes(b, 144, 81, noalloc=True), want_b)
