@@ -10,8 +10,10 @@ the ranks, each rank renders its tiles from its own copy of the scene, and the s
 gather of the tiles on rank 0 (RCCL).  The total work per step is fixed, so scaling is "strong".
 
 Rank 0 prints one JSON line.  `roofline` describes the kernel that takes most of the frame; its
-duration comes from HIP events recorded on the render stream around every launch of the timed region,
-its algorithmic work from an instrumented (untimed) frame that counts slab and triangle tests.
+duration comes from HIP events recorded on the render stream around every launch of a pass of K frames
+that follows the timed region (one frame at a time, one kernel per launch: in the timed region several
+frames overlap and independent kernels share launches), its algorithmic work from an instrumented
+(untimed) frame that counts slab and triangle tests.
 `cpu_baseline` times the CPU oracle (the restatement of the reference algorithm, compiled with the
 reference's Release flags) on a bounded sample of the same frame's rows on this machine's host cores.
 """
@@ -47,10 +49,16 @@ import raytracer_amd as R  # noqa: E402
 from raytracer_amd import _lib as L  # noqa: E402
 from raytracer_amd import tiles, workloads  # noqa: E402
 
-# Peaks from the MI355X microarchitecture guide: FP32 vector 157.3 TFLOP/s (256 CU x 4 SIMD x 32 lanes x
-# packed FMA x 2.4 GHz), HBM3E 8 TB/s.
+# Peaks from the MI355X microarchitecture guide: FP32 vector 157.3 TFLOP/s = 256 CU x 4 SIMD x 32 lanes x 2 flops
+# (one FMA) x 2.4 GHz; HBM3E 8 TB/s.  A wave64 VALU instruction takes a SIMD-32 two cycles, so the chip issues at most
+# 256 x 4 x 2.4e9 / 2 = 1228.8 G wave-level VALU instructions per second.  What the path's small scene is really served
+# from: the XCDs' L2 (34.5 TB/s aggregate) and, for records gathered at random, the Infinity Cache (8.6 TB/s measured
+# for random rows of a 38 MB table).
 PEAK_FP32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+PEAK_VALU_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2
+PEAK_L2_GBS = 34500.0
+PEAK_INFINITY_CACHE_GATHER_GBS = 8600.0
 
 # Algorithmic work per test: the reference's operation counts (one ray/AABB slab test,
 # src/boundingBox.h:257-286: 6 sub, 6 div, 3 swap-compares, 10 min/max, 2 compares = 27; plane distance,
@@ -98,6 +106,10 @@ def parse():
     ap.add_argument("--gather", choices=("u8", "f32"), default="f32",
                     help="what the ranks send to rank 0: the float framebuffer (pixel_data, what the 1e-3 parity bar is stated on), or "
                          "the 8-bit pixels the reference writes to result.ppm (a quarter of the bytes; timed as other_gather)")
+    ap.add_argument("--exchange", choices=("all_to_all", "gather", "rotate"), default="all_to_all",
+                    help="several GPUs: how a frame's row tiles come together.  all_to_all: frames in batches of N, frame k whole on rank "
+                         "k mod N, ONE all-to-all per batch (every rank's shares leave over all its xGMI links at once); gather: one gather "
+                         "per frame to rank 0 (every share crosses one link, one frame after the other); rotate: one gather per frame to rank k mod N")
     ap.add_argument("--builder", type=int, default=0, help="0 = host SAH builder, 1 = on-GPU Morton-order builder")
     ap.add_argument("--shadow-rays", type=int, default=0, help="0 = candidate grids when possible, 1 = shadow rays walk the BVH")
     ap.add_argument("--primary-rays", type=int, default=0, help="0 = screen binning, 1 = primary rays walk the BVH")
@@ -307,8 +319,13 @@ def main():
         # every rank with the file writer's expression (a quarter of the float framebuffer's bytes); --gather f32
         # sends the floats instead.
         def make_pipeline(as_bytes):
-            pipe = tiles.GatherPipeline(mine, W, 3, dev, dtype=torch.uint8 if as_bytes else torch.float32, depth=max(in_flight, a.pipeline_depth),
-                                        rehearse=not use_dist, collective_alone=use_dist)
+            dt = torch.uint8 if as_bytes else torch.float32
+            if a.exchange == "all_to_all":  # `depth` counts batches of `world` frames there
+                pipe = tiles.AllToAllPipeline(mine, W, 3, dev, dtype=dt, depth=max(2, -(-max(in_flight, a.pipeline_depth) // max(world, 1))),
+                                              rehearse=not use_dist, collective_alone=use_dist)
+            else:
+                pipe = tiles.GatherPipeline(mine, W, 3, dev, dtype=dt, depth=max(in_flight, a.pipeline_depth),
+                                            rehearse=not use_dist, collective_alone=use_dist, rotate=a.exchange == "rotate")
             bufs = [torch.zeros((max(rows, 1), W, 3), dtype=torch.float32, device=dev) for _ in range(in_flight)] if as_bytes else None
 
             def frame(p):
@@ -467,8 +484,10 @@ def main():
                 "samples_per_light": 1 + w["soft_points"], "max_reflections": w["max_reflections"],
                 "rays_per_frame": {"primary": int(rays[0].item()), "shadow": int(rays[1].item()), "bounce": int(rays[2].item())},
                 "parallelism": ("one GPU, no exchange" if world == 1 else
-                                "row tiles of %d rows round-robin over %d GPUs, one %s gather per frame, overlapped with the next frames" %
-                                (a.row_tile, world, "8-bit (PPM pixels)" if a.gather == "u8" else "float32")),
+                                "row tiles of %d rows round-robin over %d GPUs, %s of %s pixels, overlapped with the next frames" %
+                                (a.row_tile, world, {"all_to_all": "one all-to-all per %d frames (frame k whole on rank k mod %d)" % (world, world),
+                                                     "gather": "one gather per frame to rank 0", "rotate": "one gather per frame to rank k mod %d" % world}[a.exchange],
+                                 "8-bit (PPM)" if a.gather == "u8" else "float32")),
                 "frames_in_flight": in_flight,
                 "shadow_rays": "per-sample candidate grids (%d face references)" % info.shadow_grid_entries if info.shadow_grid_entries else "BVH walk",
                 "bvh": {"nodes": int(info.num_nodes), "leaves": int(info.num_leaves), "depth": int(info.depth),
@@ -514,12 +533,32 @@ def main():
                                "algorithmic_bytes_per_launch": round(bytes_launch),
                                "avg_launch_ms": round(per_launch_ms, 4), "launches_per_frame": launches_per_frame,
                                "share_of_frame": round(group_ms[k] / max(kmax[6].item(), 1e-9), 3),
-                               "note": "algorithmic bytes are mostly served by L2 / Infinity Cache (the scene is %.1f MB); avg_launch_ms: HIP events, "
+                               "note": "frac = algorithmic bytes / time against HBM's 8 TB/s as the bench contract defines it; those bytes are re-reads "
+                                       "served by L2 / Infinity Cache (the scene is %.1f MB), so frac is no bound and can pass 1 on large frames: "
+                                       "hbm_side_frac (counter bytes) and cache_level are the rates against what really serves them; avg_launch_ms: HIP events, "
                                        "one frame at a time on one stream after the timed region, one kernel per launch and each alone on the GPU "
                                        "(in the timed region %d frames overlap, and the shadow rays of a level share a launch with the closest hits "
                                        "of the next: shadow_walk_kernel)" % (info.device_bytes / 1e6, in_flight)}
             if traffic is not None:
                 out["roofline"]["traffic_unit"] = "bytes/launch at the L2's memory side, (2*FETCH_SIZE + WRITE_SIZE) KiB, from profiles/" + traffic_src
+                out["roofline"]["hbm_side_GBs"] = round(traffic / (per_launch_ms * 1e-3) / 1e9, 1)
+                out["roofline"]["hbm_side_frac"] = round(traffic / (per_launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+            # The algorithmic bytes are re-reads of a scene of a few MB to a few hundred MB: they come out of L2 and the Infinity
+            # Cache, so `frac` (against HBM, as the bench contract asks) bounds nothing and may exceed 1 on a large frame; the
+            # same rate against the levels that serve it, and the instruction issue rate the kernel really runs against:
+            out["roofline"]["cache_level"] = {"achieved_GBs": round(ach_b, 1), "l2_peak_GBs": PEAK_L2_GBS, "frac_of_l2": round(ach_b / PEAK_L2_GBS, 4),
+                                              "infinity_cache_gather_GBs": PEAK_INFINITY_CACHE_GATHER_GBS,
+                                              "frac_of_infinity_cache_gather": round(ach_b / PEAK_INFINITY_CACHE_GATHER_GBS, 4)}
+            prof = profile_table(name)
+            insts = None if prof is None else prof["per_launch"].get((closest_key, shadow_key, raster_key)[k], {})
+            if insts and insts.get("valu_wave_insts"):
+                rate = insts["valu_wave_insts"] / (per_launch_ms * 1e-3)
+                out["roofline"]["issue"] = {"valu_wave_insts_per_launch": insts["valu_wave_insts"], "lanes_per_valu_inst": insts.get("lanes_per_valu_inst"),
+                                            "issue_frac": round(rate / PEAK_VALU_WAVE_INSTS_PER_S, 4),
+                                            "active_lane_frac": round(rate / PEAK_VALU_WAVE_INSTS_PER_S * insts.get("lanes_per_valu_inst", 64.0) / 64.0, 4),
+                                            "peak_wave_insts_per_s": PEAK_VALU_WAVE_INSTS_PER_S,
+                                            "note": "wave-level VALU instructions of one launch (profiles/, PMC) over avg_launch_ms against 256 CU x 4 SIMD x "
+                                                    "2.4 GHz / 2 cycles; active_lane_frac = the same weighted by the lanes that were switched on"}
             # the same figures for all three groups, so that the runner-up shows as well (on the 1080p bunny the closest-hit walk and
             # the two shadow launches are within a few per cent of each other, and which one leads differs from box to box)
             names_all = ("closest_hits", "shadow_rays", "primary_rays_screen_space")
@@ -533,10 +572,16 @@ def main():
                 tr, _ = pmc_traffic(name, keys_all[g])
                 gb = byts[g] / lpf / (ms_l * 1e-3) / 1e9
                 tf = flops[g] / lpf / (ms_l * 1e-3) / 1e12
-                out["roofline_all"][names_all[g]] = {"kernel": keys_all[g], "avg_launch_ms": round(ms_l, 4), "launches_per_frame": lpf,
-                                                     "hbm_GBs": round(gb, 1), "hbm_frac": round(gb / PEAK_HBM_GBS, 4),
-                                                     "valu_TFLOPs": round(tf, 3), "valu_frac": round(tf / PEAK_FP32_TFLOPS, 4),
-                                                     "traffic": None if tr is None else round(tr)}
+                row = {"kernel": keys_all[g], "avg_launch_ms": round(ms_l, 4), "launches_per_frame": lpf,
+                       "algorithmic_GBs": round(gb, 1), "hbm_frac": round(gb / PEAK_HBM_GBS, 4), "l2_frac": round(gb / PEAK_L2_GBS, 4),
+                       "valu_TFLOPs": round(tf, 3), "valu_frac": round(tf / PEAK_FP32_TFLOPS, 4),
+                       "traffic": None if tr is None else round(tr)}
+                if tr is not None:
+                    row["hbm_side_frac"] = round(tr / (ms_l * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+                pi = None if prof is None else prof["per_launch"].get(keys_all[g])
+                if pi and pi.get("valu_wave_insts"):
+                    row["issue_frac"] = round(pi["valu_wave_insts"] / (ms_l * 1e-3) / PEAK_VALU_WAVE_INSTS_PER_S, 4)
+                out["roofline_all"][names_all[g]] = row
             ach = flops_launch / (per_launch_ms * 1e-3) / 1e12
             out["roofline_valu"] = {"kernel": kname, "bound": "valu", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                                     "frac": round(ach / PEAK_FP32_TFLOPS, 4), "algorithmic_flops_per_launch": round(flops_launch)}
@@ -585,11 +630,30 @@ def main():
             locked_ms = host_ms(p_rgb.value, p_fid.value)
             lib.rtamd_host_free(p_rgb)
             lib.rtamd_host_free(p_fid)
-            out["host_boundary"] = {"ms_per_frame": round(locked_ms, 3), "Mrays_per_s": round(rays_frame / locked_ms / 1e3, 1),
-                                    "ms_per_frame_pageable_buffers": round(pageable_ms, 3),
-                                    "note": "rtamd_render (blocking, one frame at a time) with host output buffers, PCIe download of rgb + face "
-                                            "ids (%.1f MB) included; ms_per_frame: buffers from rtamd_host_alloc (page-locked), the other figure: "
-                                            "ordinary malloc'ed buffers" % (H * W * 16 / 1e6)}
+            # ... and what Flyscene::raytraceScene itself needs of a frame: the 8-bit pixels of result.ppm (rtamd_render_ppm,
+            # quantised on the device; a quarter of the float framebuffer's bytes cross the link, no face ids)
+            p_pix = C.c_void_p()
+            L.check(lib.rtamd_host_alloc(C.byref(p_pix), H * W * 3), "rtamd_host_alloc")
+            exact = C.c_int32(0)
+
+            def ppm_frame():
+                L.check(lib.rtamd_render_ppm((fly1 or fly).scene, C.byref(cam), C.byref(plain), p_pix, C.byref(exact), None), "rtamd_render_ppm")
+
+            ppm_frame()
+            ppm_frame()
+            ts = []
+            for _ in range(25):
+                t0 = time.perf_counter()
+                ppm_frame()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            ppm_ms = sorted(ts)[len(ts) // 2]
+            lib.rtamd_host_free(p_pix)
+            out["host_boundary"] = {"ms_per_frame": round(ppm_ms, 3), "Mrays_per_s": round(rays_frame / ppm_ms / 1e3, 1),
+                                    "ms_per_frame_float_planes": round(locked_ms, 3), "ms_per_frame_float_planes_pageable": round(pageable_ms, 3),
+                                    "note": "blocking entry points, one frame at a time, PCIe download included.  ms_per_frame: rtamd_render_ppm, the "
+                                            "path of Flyscene::raytraceScene (the 8-bit pixels of result.ppm, %.1f MB, page-locked buffer; bytes exact: %d); "
+                                            "ms_per_frame_float_planes: rtamd_render with rgb + face ids as floats / ints (%.1f MB) into page-locked "
+                                            "buffers, ..._pageable: into ordinary malloc'ed buffers" % (H * W * 3 / 1e6, exact.value, H * W * 16 / 1e6)}
         if piped:
             out["other_gather"] = {"payload": "float32" if a.gather == "u8" else "8-bit (PPM pixels)",
                                    "ms_per_step": round(other_elapsed / a.steps * 1e3, 4),

@@ -251,6 +251,15 @@ int32_t rtamd_global_row(const rtamd_render_params *p, int32_t local_row);
 int rtamd_render(rtamd_scene *scene, const rtamd_camera *cam, const rtamd_render_params *p, float *rgb,
                  int32_t *face_id, rtamd_stats *stats);
 
+/* The frame as Flyscene::raytraceScene leaves it: not pixel_data but what writePPMImage makes of it
+ * (src/flyscene.cpp:445; utils/ppmIO.hpp:203), pixels[i] = min(255, (int)(255 * rgb[i])), local_rows*width*3 bytes, quantised
+ * on the device so that a quarter of the float framebuffer's bytes cross the host link.  Blocking, host buffer (page-locked
+ * or not, as for rtamd_render).  *exact (may be NULL) = 1 when the bytes are what the reference prints for every channel;
+ * 0 when some channel is <= -1/255, not a number or beyond the int range -- the reference prints a negative number or is
+ * undefined there -- and the caller who cares renders that frame with rtamd_render instead. */
+int rtamd_render_ppm(rtamd_scene *scene, const rtamd_camera *cam, const rtamd_render_params *p, uint8_t *pixels, int32_t *exact,
+                     rtamd_stats *stats);
+
 /* Page-locked host memory for the output planes of rtamd_render: the download then goes straight into the caller's
  * buffer at the link's rate (any page-locked buffer does: hipHostMalloc, hipHostRegister); pageable buffers work too
  * and cost an extra host copy.  Stands where the reference allocates pixel_data (src/flyscene.cpp:399-403). */

@@ -116,6 +116,7 @@ SYMBOLS = {
     "rtamd_local_rows": (C.c_int32, [C.POINTER(RenderParams)]),
     "rtamd_global_row": (C.c_int32, [C.POINTER(RenderParams), C.c_int32]),
     "rtamd_render": (C.c_int, [_P, C.POINTER(Camera), C.POINTER(RenderParams), _fp, _ip, C.POINTER(Stats)]),
+    "rtamd_render_ppm": (C.c_int, [_P, C.POINTER(Camera), C.POINTER(RenderParams), _P, C.POINTER(C.c_int32), C.POINTER(Stats)]),
     "rtamd_host_alloc": (C.c_int, [C.POINTER(_P), C.c_uint64]),
     "rtamd_host_free": (C.c_int, [_P]),
     "rtamd_render_device": (C.c_int, [_P, C.POINTER(Camera), C.POINTER(RenderParams), _P, _P, _P, _P]),

@@ -120,6 +120,8 @@ struct rtamd_scene {
     float *d_rgb = nullptr;
     int32_t *d_face = nullptr;
     size_t staging_pixels = 0;
+    uint8_t *d_bytes = nullptr; // rtamd_render_ppm: the quantised frame, and behind it the int that says whether bytes suffice
+    size_t bytes_pixels = 0;
     void *h_staging = nullptr; // page-locked host memory the planes are downloaded into when the caller's buffers are pageable
     size_t h_staging_bytes = 0;
     // bookkeeping of the most recent frame
@@ -663,7 +665,7 @@ int rtamd_scene_destroy(rtamd_scene *s) {
     if (!s) return RTAMD_OK;
     void *bufs[] = {s->d_tri_of_rank, s->d_cluster_box, s->d_planes, s->d_nodes, s->d_tris,  s->d_shade,  s->d_materials, s->d_light_pos, s->d_samples,
                     s->d_spheres, s->d_texels, s->d_tex_info, s->d_grid_headers, s->d_grid_cells, s->d_grid_entries,
-                    s->d_rgb, s->d_face};
+                    s->d_rgb, s->d_face, s->d_bytes};
     (void)hipDeviceSynchronize(); // frames may still be in flight on the caller's streams
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -1279,6 +1281,58 @@ int rtamd_render(rtamd_scene *s, const rtamd_camera *cam, const rtamd_render_par
     };
     if (!rgb_direct) host_copy(rgb, stage_rgb, pixels * 12);
     if (face_id && !face_direct) host_copy(face_id, stage_face, pixels * 4);
+    if (stats) return rtamd_render_stats(s, stats);
+    return RTAMD_OK;
+}
+
+int rtamd_render_ppm(rtamd_scene *s, const rtamd_camera *cam, const rtamd_render_params *p, uint8_t *pixels, int32_t *exact, rtamd_stats *stats) {
+    int rc = check_params(s, cam, p);
+    if (rc != RTAMD_OK) return rc;
+    if (!pixels) return fail(RTAMD_ERR_INVALID, "null pixel output");
+    if (exact) *exact = 1;
+    const size_t npix = (size_t)rtamd_local_rows(p) * (size_t)p->width;
+    if (npix == 0) {
+        if (stats) std::memset(stats, 0, sizeof *stats);
+        return RTAMD_OK;
+    }
+    if (s->staging_pixels < npix) {
+        if (s->d_rgb) HIP_TRY(hipFree(s->d_rgb));
+        if (s->d_face) HIP_TRY(hipFree(s->d_face));
+        s->d_rgb = nullptr, s->d_face = nullptr, s->staging_pixels = 0;
+        HIP_TRY(hipMalloc((void **)&s->d_rgb, npix * 12));
+        HIP_TRY(hipMalloc((void **)&s->d_face, npix * 4));
+        s->staging_pixels = npix;
+    }
+    const size_t nbytes = (npix * 3 + 15) & ~(size_t)15; // the flag sits behind the image, 16-byte aligned: one download brings both
+    if (s->bytes_pixels < npix) {
+        if (s->d_bytes) HIP_TRY(hipFree(s->d_bytes));
+        s->d_bytes = nullptr, s->bytes_pixels = 0;
+        HIP_TRY(hipMalloc((void **)&s->d_bytes, nbytes + 16));
+        s->bytes_pixels = npix;
+    }
+    hipPointerAttribute_t attr;
+    bool direct = hipPointerGetAttributes(&attr, pixels) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!direct) (void)hipGetLastError(); // an ordinary host pointer is reported as an error
+    const size_t need = (direct ? 0 : nbytes) + 16;
+    if (s->h_staging_bytes < need) {
+        if (s->h_staging) HIP_TRY(hipHostFree(s->h_staging));
+        s->h_staging = nullptr, s->h_staging_bytes = 0;
+        HIP_TRY(hipHostMalloc(&s->h_staging, need, hipHostMallocDefault));
+        s->h_staging_bytes = need;
+    }
+    int *const d_flag = (int *)(s->d_bytes + nbytes);
+    volatile int *const h_flag = (volatile int *)s->h_staging;
+    uint8_t *const h_pixels = direct ? pixels : (uint8_t *)s->h_staging + 16;
+    HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), nullptr));
+    rc = rtamd_render_device(s, cam, p, s->d_rgb, nullptr, nullptr, nullptr);
+    if (rc != RTAMD_OK) return rc;
+    launch_quantize_checked(s->d_rgb, s->d_bytes, npix * 3, d_flag, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_pixels, s->d_bytes, npix * 3, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync((void *)h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    if (!direct) std::memcpy(pixels, h_pixels, npix * 3);
+    if (exact) *exact = *h_flag ? 0 : 1;
     if (stats) return rtamd_render_stats(s, stats);
     return RTAMD_OK;
 }

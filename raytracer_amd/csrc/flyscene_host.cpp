@@ -504,6 +504,35 @@ bool write_ppm_binary(const std::string &path, const float *rgb, int width, int 
     return true;
 }
 
+// The same two files from pixels that are quantised already (rtamd_render_ppm: bytes = min(255, (int)(255 * c)) with no channel
+// negative): the text of utils/ppmIO.hpp:188-209 from a table of the 256 possible "value + blank" strings, or the bytes as they are.
+bool write_ppm_bytes(const std::string &path, const unsigned char *pixels, int width, int height, bool binary) {
+    std::FILE *out = std::fopen(path.c_str(), binary ? "wb" : "w");
+    if (!out) return false;
+    std::fprintf(out, "%s\n%d %d\n255\n", binary ? "P6" : "P3", width, height);
+    if (binary) {
+        std::fwrite(pixels, 1, (size_t)width * height * 3, out);
+    } else {
+        char text[256][5];
+        int len[256];
+        for (int v = 0; v < 256; ++v) {
+            len[v] = std::snprintf(text[v], sizeof text[v], "%d", v);
+            text[v][len[v]++] = ' ';
+        }
+        std::string buf;
+        buf.reserve((size_t)width * 12 + 16);
+        for (int j = 0; j < height; ++j) {
+            buf.clear();
+            const unsigned char *row = pixels + (size_t)j * width * 3;
+            for (int i = 0; i < width * 3; ++i) buf.append(text[row[i]], (size_t)len[row[i]]);
+            buf.push_back('\n');
+            std::fwrite(buf.data(), 1, buf.size(), out);
+        }
+    }
+    std::fclose(out);
+    return true;
+}
+
 // utils/ppmIO.hpp:188-209: ASCII P3, each channel min(255, (int)(255 * c)), one text line per row.
 bool write_ppm(const std::string &path, const float *rgb, int width, int height) {
     std::FILE *out = std::fopen(path.c_str(), "w");
@@ -663,6 +692,7 @@ void Flycamera::fill(rtamd_camera &c) const {
 // Flyscene
 // ------------------------------------------------------------------------------------------------
 Flyscene::~Flyscene() {
+    if (pixel_bytes_) rtamd_host_free(pixel_bytes_);
     if (scene_) rtamd_scene_destroy(scene_);
 }
 
@@ -825,35 +855,45 @@ int Flyscene::render(float *rgb, int32_t *face_id, rtamd_stats *stats) {
     return rtamd_render(scene_, &cam, &params, rgb, face_id, stats);
 }
 
+// src/flyscene.cpp:381-459.  All the reference keeps of a frame is result.ppm, so the frame comes back from the device as
+// the file's 8-bit pixels (rtamd_render_ppm: a quarter of the bytes of pixel_data over the host link) into a page-locked
+// buffer this object keeps; only a frame with a channel the bytes cannot express (negative, not a number) is fetched as
+// floats, as the reference holds it, and written from those.
 int Flyscene::raytraceScene() {
     const std::array<int, 2> size = flycamera.getViewportSize(); // :394
     if (size[0] != params.width || size[1] != params.height) return RTAMD_ERR_INVALID;
+    if (!scene_) return RTAMD_ERR_INVALID;
     rtamd_render_params full = params;
     full.num_parts = 1, full.part = 0;
-    const rtamd_render_params saved = params;
-    params = full;
-    // pixel_data (src/flyscene.cpp:399-403) in page-locked memory: the frame is downloaded straight into it
-    void *locked = nullptr;
-    int rc = rtamd_host_alloc(&locked, (uint64_t)size[0] * size[1] * 3 * sizeof(float));
-    if (rc != RTAMD_OK) {
-        params = saved;
-        return rc;
+    const size_t nbytes = (size_t)size[0] * (size_t)size[1] * 3;
+    if (pixel_bytes_size_ < nbytes) {
+        if (pixel_bytes_) rtamd_host_free(pixel_bytes_);
+        pixel_bytes_ = nullptr, pixel_bytes_size_ = 0;
+        const int rc = rtamd_host_alloc(&pixel_bytes_, (uint64_t)nbytes);
+        if (rc != RTAMD_OK) return rc;
+        pixel_bytes_size_ = nbytes;
     }
-    struct Release {
-        void *p;
-        ~Release() { rtamd_host_free(p); }
-    } release{locked};
-    float *const pixel_data_ptr = (float *)locked;
-    rc = render(pixel_data_ptr, nullptr, nullptr);
-    params = saved;
+    flycamera.reComputeViewMatrix(); // tracePixels does this first, src/flyscene.cpp:806
+    rtamd_camera cam;
+    flycamera.fill(cam);
+    int32_t exact = 1;
+    int rc = rtamd_render_ppm(scene_, &cam, &full, (uint8_t *)pixel_bytes_, &exact, nullptr);
     if (rc != RTAMD_OK) return rc;
     auto ends_with = [&](const char *suffix) {
         const size_t n = std::strlen(suffix);
         return output_path.size() >= n && output_path.compare(output_path.size() - n, n, suffix) == 0;
     };
     const bool binary = ends_with(".p6.ppm") || ends_with(".pnm");
+    if (exact) {
+        if (!output_path.empty() && !write_ppm_bytes(output_path, (const unsigned char *)pixel_bytes_, size[0], size[1], binary)) return RTAMD_ERR_INVALID;
+        return RTAMD_OK;
+    }
+    // pixel_data (src/flyscene.cpp:399-403) as floats, for the writer that prints what the reference prints of them
+    std::vector<float> pixel_data((size_t)size[0] * (size_t)size[1] * 3);
+    rc = rtamd_render(scene_, &cam, &full, pixel_data.data(), nullptr, nullptr);
+    if (rc != RTAMD_OK) return rc;
     if (!output_path.empty() &&
-        !(binary ? write_ppm_binary(output_path, pixel_data_ptr, size[0], size[1]) : write_ppm(output_path, pixel_data_ptr, size[0], size[1])))
+        !(binary ? write_ppm_binary(output_path, pixel_data.data(), size[0], size[1]) : write_ppm(output_path, pixel_data.data(), size[0], size[1])))
         return RTAMD_ERR_INVALID;
     return RTAMD_OK;
 }

@@ -54,6 +54,8 @@ bool load_ppm_texture(const std::string &path, HostTexture &tex, std::string &er
 bool load_material_textures(HostMesh &mesh, std::string &error);                       // src/flyscene.cpp:52-71
 void finish_mesh(HostMesh &mesh, bool have_normals);
 bool write_ppm(const std::string &path, const float *rgb, int width, int height);
+// The same files (P3 text, or P6 with binary = true) from pixels already quantised to the file's 8 bits.
+bool write_ppm_bytes(const std::string &path, const unsigned char *pixels, int width, int height, bool binary);
 // Same quantisation as write_ppm, written as binary P6 (a tenth of the bytes, no text formatting).
 bool write_ppm_binary(const std::string &path, const float *rgb, int width, int height);
 
@@ -129,6 +131,8 @@ private:
     Flycamera flycamera;
     rtamd_scene *scene_ = nullptr;
     bool initialized_ = false;
+    void *pixel_bytes_ = nullptr; // page-locked: the 8-bit frame raytraceScene downloads
+    size_t pixel_bytes_size_ = 0;
 };
 
 } // namespace rtamd

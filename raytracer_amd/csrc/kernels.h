@@ -40,6 +40,7 @@ void launch_shade_compact(bool primary, const DeviceScene &sc, const FrameConst 
 void launch_misses(const FrameConst &fc, const Workspace &ws, int stage, int depth, float *rgb, int expect, hipStream_t stream);
 void launch_scale(float *rgb, size_t n, float divisor, hipStream_t stream);
 void launch_quantize(const float *rgb, uint8_t *out, size_t n, hipStream_t stream);
+void launch_quantize_checked(const float *rgb, uint8_t *out, size_t n, int *inexact, hipStream_t stream);
 void launch_assemble(const void *src, void *dst, int width, int height, int channels, int row_tile, int num_parts, hipStream_t stream);
 
 // Smallest widening (pixels) of projected boxes and triangles; see the error bound at RT_BIN_MARGIN in kernels.hip.

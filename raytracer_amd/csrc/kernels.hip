@@ -642,16 +642,24 @@ __device__ __forceinline__ unsigned long long hit_key(float t, int rank) {
     return ((unsigned long long)(unsigned)__float_as_int(t) << 32) | (unsigned long long)(unsigned)(0x7fffffff - rank);
 }
 
+// LDS of one wave of the closest-hit walk (passed in by the kernel, so that a kernel whose workgroups take different roles can
+// lay the roles' LDS over each other).
+struct WalkLds {
+    unsigned long long key[64]; // per ray of the wave: best (distance, rank) published so far
+    int stack[(kLdsStack + kLeafQueueClosest) * 64];
+    int tri[64];                // ... and its record
+    int cut[64];                // ... and the bits of the nearest distance accepted by any lane, published or not
+    int donor[64];
+};
+
 // (`block` of `nblocks`: the launch's block index and grid, or this kernel's share of a launch it shares with another)
 template <int MODE, bool COUNT>
 __device__ __forceinline__ void walk_steal_body(const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, int total_static,
-                                                int block, int nblocks) {
+                                                int block, int nblocks, WalkLds &lds) {
     static_assert(MODE == kPrimary || MODE == kQueue, "closest-hit modes only");
-    __shared__ int s_stack[(kLdsStack + kLeafQueueClosest) * 64];
-    __shared__ unsigned long long s_key[64]; // per ray of the wave: best (distance, rank) published so far
-    __shared__ int s_tri[64];                // ... and its record
-    __shared__ int s_cut[64];                // ... and the bits of the nearest distance accepted by any lane, published or not
-    __shared__ int s_donor[64];
+    int *const s_stack = lds.stack;
+    unsigned long long *const s_key = lds.key;
+    int *const s_tri = lds.tri, *const s_cut = lds.cut, *const s_donor = lds.donor;
     int deep[kStackEntries - kLdsStack > 0 ? kStackEntries - kLdsStack : 1];
     const int lane = (int)threadIdx.x;
     int *const stack = s_stack + lane;
@@ -874,7 +882,8 @@ __device__ __forceinline__ void walk_steal_body(const DeviceScene &sc, const Fra
 
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_steal_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth, int total_static) {
-    walk_steal_body<MODE, COUNT>(sc, fc, ws, stage, depth, total_static, (int)blockIdx.x, (int)gridDim.x);
+    __shared__ WalkLds lds;
+    walk_steal_body<MODE, COUNT>(sc, fc, ws, stage, depth, total_static, (int)blockIdx.x, (int)gridDim.x, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1606,6 +1615,9 @@ static_assert(RT_SHADOW_BATCH >= 1 && RT_SHADOW_BATCH <= 8, "the entry arrays ar
 #ifndef RT_SHADOW_XCD
 #define RT_SHADOW_XCD 1
 #endif
+#ifndef RT_SHADOW_CORNERS_AHEAD
+#define RT_SHADOW_CORNERS_AHEAD 0
+#endif
 template <bool COUNT>
 __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth, int block, int nblocks) {
     const int lane = (int)threadIdx.x;
@@ -1694,6 +1706,26 @@ __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const Fr
                         pn[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         if (e + k < end && !(__int_as_float(ent[k].y) < z)) pn[k] = *(const float4 *)((const char *)sc.planes + ((unsigned)ent[k].x << 4));
                     }
+#if RT_SHADOW_CORNERS_AHEAD
+                    // Diagnostic build only (never the default): the corners of the batch's first candidates fetched together
+                    // with the planes, whatever the lane's list length and whatever the plane test will say -- the variant that
+                    // once ended in a memory fault.  Every record index such a fetch is formed from is checked against the
+                    // number of records first, also for lanes past their list's end; a bad one is reported and skipped.
+                    float4 ahead[RT_SHADOW_CORNERS_AHEAD][3];
+#pragma unroll
+                    for (int k = 0; k < RT_SHADOW_CORNERS_AHEAD; ++k) {
+                        const unsigned idx = (unsigned)ent[k].x;
+                        if (idx >= (unsigned)sc.num_records) {
+                            printf("rtamd diagnostic: record index %u of %d formed from entry %d (+%d) of a list [%d, %d), lane %d sub %d\n", idx, sc.num_records, e, k, begin,
+                                   end, lane, sub);
+                            ahead[k][0] = ahead[k][1] = ahead[k][2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            continue;
+                        }
+                        const float4 *const rec = (const float4 *)(records + (idx << 6));
+                        ahead[k][0] = rec[1], ahead[k][1] = rec[2], ahead[k][2] = rec[3];
+                        keep(ahead[k][0]), keep(ahead[k][1]), keep(ahead[k][2]);
+                    }
+#endif
                     bool behind = false;
 #pragma unroll
                     for (int k = 0; k < RT_SHADOW_BATCH; ++k) {
@@ -1708,9 +1740,15 @@ __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const Fr
                         const float t = (pn[k].w - dot(o, n)) / dot(d, n);
                         if (!(t >= fc.t_eps && t <= tbest)) continue; // also rejects NaN (see file header)
                         const float4 *const rec = (const float4 *)(records + ((unsigned)i << 6));
+#if RT_SHADOW_CORNERS_AHEAD
+                        const float4 p0 = k < RT_SHADOW_CORNERS_AHEAD ? ahead[k < RT_SHADOW_CORNERS_AHEAD ? k : 0][0] : rec[1];
+                        const float4 p1 = k < RT_SHADOW_CORNERS_AHEAD ? ahead[k < RT_SHADOW_CORNERS_AHEAD ? k : 0][1] : rec[2];
+                        const float4 p2 = k < RT_SHADOW_CORNERS_AHEAD ? ahead[k < RT_SHADOW_CORNERS_AHEAD ? k : 0][2] : rec[3];
+#else
                         const float4 p0 = rec[1];
                         const float4 p1 = rec[2];
                         const float4 p2 = rec[3];
+#endif
                         if (COUNT) ++w_edge;
                         const V3 v0 = mk(p0.x, p0.y, p0.z), v1 = mk(p1.x, p1.y, p1.z), v2 = mk(p2.x, p2.y, p2.z);
                         const V3 at = o + t * d;
@@ -1735,8 +1773,14 @@ __device__ __forceinline__ void shadow_grid_body(const DeviceScene &sc, const Fr
     if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 1);
 }
 
+
+// (eight waves per SIMD need the kernel's scalar registers to stay within 96 as well: the wave-uniform grid header and scene
+// pointers live there)
+#ifndef RT_SHADOW_MIN_WAVES
+#define RT_SHADOW_MIN_WAVES RT_WAVES_PER_SIMD
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(64) void shadow_grid_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth) {
+__global__ __launch_bounds__(64, RT_SHADOW_MIN_WAVES) void shadow_grid_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth) {
     shadow_grid_body<COUNT>(sc, fc, ws, stage, depth, (int)blockIdx.x, (int)gridDim.x);
 }
 
@@ -1748,8 +1792,9 @@ __global__ __launch_bounds__(64) void shadow_grid_kernel(DeviceScene sc, FrameCo
 template <bool COUNT>
 __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void shadow_walk_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int stage, int depth,
                                                                             int walk_blocks) {
+    __shared__ WalkLds lds;
     if ((int)blockIdx.x < walk_blocks)
-        walk_steal_body<kQueue, COUNT>(sc, fc, ws, stage + 1, depth + 1, 0, (int)blockIdx.x, walk_blocks);
+        walk_steal_body<kQueue, COUNT>(sc, fc, ws, stage + 1, depth + 1, 0, (int)blockIdx.x, walk_blocks, lds);
     else
         shadow_grid_body<COUNT>(sc, fc, ws, stage, depth, (int)blockIdx.x - walk_blocks, (int)gridDim.x - walk_blocks);
 }
@@ -2234,6 +2279,26 @@ __global__ void quantize_kernel(const float *rgb, uint8_t *out, size_t n) {
     }
 }
 
+// The same bytes, and beside them whether they say all there is to say: writePPMImage prints min(255, (int)(255 * c)), which
+// is negative for c <= -1/255 and undefined for a NaN or a value beyond the int range; a byte cannot hold either.  Any such
+// channel sets *inexact (an int the caller cleared), and the caller falls back to the float framebuffer.
+__global__ void quantize_checked_kernel(const float *rgb, uint8_t *out, size_t n, int *inexact) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    bool odd = false;
+    if (i + 4 <= n) {
+        const float4 v = *(const float4 *)(rgb + i);
+        *(unsigned *)(out + i) = ppm_byte(v.x) | (ppm_byte(v.y) << 8) | (ppm_byte(v.z) << 16) | (ppm_byte(v.w) << 24);
+        const float lo = fminf(fminf(v.x, v.y), fminf(v.z, v.w)), hi = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+        odd = !(255.0f * lo > -1.0f) || !(255.0f * hi < 2147483648.0f) || v.x != v.x || v.y != v.y || v.z != v.z || v.w != v.w;
+    } else {
+        for (size_t k = i; k < n; ++k) {
+            out[k] = (uint8_t)ppm_byte(rgb[k]);
+            odd = odd || !(255.0f * rgb[k] > -1.0f) || !(255.0f * rgb[k] < 2147483648.0f);
+        }
+    }
+    if (__ballot(odd) != 0ull && (threadIdx.x & 63) == 0) *inexact = 1; // (plain store: every writer stores the same value)
+}
+
 // Packed part-major rows -> image rows (4-byte elements).
 __global__ void assemble_kernel(const uint32_t *src, uint32_t *dst, int width, int height, int channels, int row_tile, int num_parts) {
     const size_t row_elems = (size_t)width * channels;
@@ -2508,6 +2573,12 @@ void launch_quantize(const float *rgb, uint8_t *out, size_t n, hipStream_t strea
     if (n == 0) return;
     const size_t threads = (n + 3) / 4;
     quantize_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, stream>>>(rgb, out, n);
+}
+
+void launch_quantize_checked(const float *rgb, uint8_t *out, size_t n, int *inexact, hipStream_t stream) {
+    if (n == 0) return;
+    const size_t threads = (n + 3) / 4;
+    quantize_checked_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, stream>>>(rgb, out, n, inexact);
 }
 
 void launch_assemble(const void *src, void *dst, int width, int height, int channels, int row_tile, int num_parts, hipStream_t stream) {

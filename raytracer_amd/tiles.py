@@ -1,10 +1,16 @@
-"""Row-tile partition of a frame across the GPUs of one node and the single gather that follows.
+"""Row-tile partition of a frame across the GPUs of one node and the one exchange that follows.
 
 The reference splits rows over CPU threads (`y = tid; y += N`, src/flyscene.cpp:809).  Here the image
 is cut into tiles of `row_tile` rows, tile k goes to rank k % world; every rank holds the whole
-read-only scene and renders its tiles into a packed buffer.  The only exchange is one gather of the
-packed buffers to rank 0 (torch.distributed.gather: on the nccl backend, i.e. RCCL, that is one
-grouped send/recv per peer, so the root's xGMI links are used concurrently).
+read-only scene and renders its tiles into a packed buffer.  The only exchange brings the packed
+buffers of a frame together on one rank, in one of two forms:
+
+* GatherPipeline: one gather per frame (torch.distributed.gather: on the nccl backend, i.e. RCCL, one
+  grouped send/recv per peer) to a fixed rank, or to rank k % world for frame k.  Every frame costs
+  every sender its share over ONE of its links (xGMI is point to point), whichever rank is the root.
+* AllToAllPipeline: frames in batches of `world`; frame b * world + k is delivered whole on rank k by
+  ONE all-to-all per batch, in which every rank sends its shares of the batch's frames over all its
+  links at once.  The same bytes per frame, a `world`-th of the time on the wire.
 """
 import contextlib
 import ctypes as C
@@ -127,10 +133,15 @@ class GatherPipeline:
     `rehearse` (one process only) puts a device copy on a side stream where the collective would be, with the same
     waits between the streams: the stream topology of a several-GPU run on one GPU."""
 
-    def __init__(self, params, width, channels, device, dtype=torch.float32, group=None, dst=0, depth=2, rehearse=False, collective_alone=False):
+    def __init__(self, params, width, channels, device, dtype=torch.float32, group=None, dst=0, depth=2, rehearse=False, collective_alone=False,
+                 rotate=False):
+        """rotate: frame k is gathered on rank (dst + k) % world instead of always on `dst` (every rank then holds
+        receive buffers and returns the frames it was the root of, in order)."""
         self.params, self.group, self.dst = params, group, dst
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.rotate = bool(rotate) and self.world > 1
+        self.frames = 0
         # collective_alone: a group of ONE process still goes through the collective (a test of the plumbing around it)
         self.single = self.world == 1 and not (collective_alone and dist.is_initialized())
         self.depth = max(2, int(depth))
@@ -139,9 +150,10 @@ class GatherPipeline:
         shape = (self.rows_max, width, channels)
         self.send = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(self.depth)]
         self.recv = None
-        if not self.single and self.rank == dst:
+        if not self.single and (self.rank == dst or self.rotate):
             self.recv = [torch.empty((self.world,) + shape, dtype=dtype, device=device) for _ in range(self.depth)]
             self.index = index_padded.to(device)
+        self.root = [dst] * self.depth  # root of the frame that buffer b holds
         self.side = None
         if self.single and rehearse:
             self.side = torch.cuda.Stream(device)
@@ -159,7 +171,7 @@ class GatherPipeline:
         self.work[b] = None
         if self.single:
             return (self.recv if self.side is not None else self.send)[b][: self.params.height].clone()
-        if self.rank != self.dst:
+        if self.rank != self.root[b]:
             return None
         flat = self.recv[b].view((self.world * self.rows_max,) + tuple(self.send[b].shape[1:]))
         return flat.index_select(0, self.index)
@@ -184,14 +196,126 @@ class GatherPipeline:
                         self.recv[b].copy_(self.send[b])
                         self.work[b] = torch.cuda.Event()
                         self.work[b].record(self.side)
-            elif self.rank == self.dst:
-                self.work[b] = dist.gather(self.send[b], list(self.recv[b].unbind(0)), dst=self.dst, group=self.group, async_op=True)
             else:
-                self.work[b] = dist.gather(self.send[b], None, dst=self.dst, group=self.group, async_op=True)
+                root = (self.dst + self.frames) % self.world if self.rotate else self.dst
+                self.root[b] = root
+                if self.rank == root:
+                    self.work[b] = dist.gather(self.send[b], list(self.recv[b].unbind(0)), dst=root, group=self.group, async_op=True)
+                else:
+                    self.work[b] = dist.gather(self.send[b], None, dst=root, group=self.group, async_op=True)
+        self.frames += 1
         self.turn = (self.turn + 1) % self.depth
         out, self.done = self.done, None
         return out
 
     def drain(self):
         out = [self._finish((self.turn + i) % self.depth) for i in range(self.depth)]
-        return [x for x in out if x is not None] if (self.single or self.rank == self.dst) else []
+        return [x for x in out if x is not None]
+
+
+class AllToAllPipeline:
+    """Frames of a render loop in batches of `world`: every rank renders its rows of each frame of a batch into one
+    chunk of a send buffer, and ONE all-to-all per batch delivers frame b * world + k whole on rank k.  Same usage as
+    GatherPipeline, every rank alike:
+
+        pipe = AllToAllPipeline(params, width, channels, device, depth=D)
+        for k in range(frames):
+            buf = pipe.acquire(stream)     # first frame of a batch: waits (on the stream) for the exchange D batches back
+            render into buf[:local_rows]
+            image = pipe.submit(stream)    # last frame of a batch: starts the batch's exchange
+        rest = pipe.drain()                # exchanges a last, partial batch and returns the frames still under way
+
+    Every rank is the root of one frame per batch and gets its frames back in order (rank r: frames r, r + world, ...).
+    Why batches: xGMI links are point to point.  Gathering a 4K frame of float pixels, every sender moves its eighth
+    (12.4 MB) over the one link to the root while its six other links idle, and a rank's collectives run one after the
+    other; in the all-to-all the eight shares a rank holds for the batch's eight roots leave over seven links at once.
+    `depth` = batches in flight (send and receive buffers of `world` chunks each)."""
+
+    def __init__(self, params, width, channels, device, dtype=torch.float32, group=None, depth=2, rehearse=False, collective_alone=False):
+        self.params, self.group = params, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.single = self.world == 1 and not (collective_alone and dist.is_initialized())
+        self.depth = max(2, int(depth))
+        self.cuda = torch.device(device).type == "cuda"
+        rows, rows_max, index_padded, _, _ = layout(params, self.world)
+        self.rows_max = max(rows_max, 1)
+        shape = (self.world, self.rows_max, width, channels)
+        self.send = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(self.depth)]
+        self.side = torch.cuda.Stream(device) if (self.single and rehearse and self.cuda) else None
+        need_recv = not self.single or self.side is not None
+        self.recv = [torch.empty(shape, dtype=dtype, device=device) for _ in range(self.depth)] if need_recv else None
+        self.index = index_padded.to(device)
+        self.work = [None] * self.depth     # the exchange of the batch in slot b: a collective's handle, an event, or True
+        self.filled = [0] * self.depth      # frames that batch held
+        self.free = [None] * self.depth     # event: slot b's previous exchange is over and its frame assembled
+        self.rendered = [[] for _ in range(self.depth)]  # events behind the frames of the batch being rendered into slot b
+        self.slot, self.k = 0, 0
+        self.done = None
+
+    _on = staticmethod(GatherPipeline._on)
+
+    def _finish(self, b):
+        if self.work[b] is None:
+            return None
+        if self.work[b] is not True:
+            self.work[b].wait()  # the current stream waits, not the host
+        self.work[b] = None
+        if self.rank >= self.filled[b]:
+            return None  # a last, partial batch held no frame for this rank
+        src = self.recv[b] if self.recv is not None else self.send[b]
+        flat = src.view((self.world * self.rows_max,) + tuple(src.shape[2:]))
+        return flat.index_select(0, self.index)
+
+    def acquire(self, stream=None):
+        b = self.slot
+        with self._on(stream):
+            if self.k == 0:
+                self.done = self._finish(b)
+                if self.cuda:
+                    self.free[b] = torch.cuda.Event()
+                    self.free[b].record(torch.cuda.current_stream(self.send[b].device))
+            elif self.cuda and self.free[b] is not None:  # the other frames of the batch write other chunks of the same buffer
+                torch.cuda.current_stream(self.send[b].device).wait_event(self.free[b])
+        return self.send[b][self.k]
+
+    def _exchange(self, b):
+        """Starts the exchange of the batch in slot b behind every frame rendered into it (called on the stream of the last)."""
+        if self.cuda:
+            cur = torch.cuda.current_stream(self.send[b].device)
+            for ev in self.rendered[b]:
+                cur.wait_event(ev)
+        self.rendered[b] = []
+        self.filled[b] = self.k
+        if self.single:
+            self.work[b] = True
+            if self.side is not None:
+                self.side.wait_stream(torch.cuda.current_stream(self.send[b].device))
+                with torch.cuda.stream(self.side):
+                    self.recv[b].copy_(self.send[b])
+                    self.work[b] = torch.cuda.Event()
+                    self.work[b].record(self.side)
+        else:
+            self.work[b] = dist.all_to_all_single(self.recv[b].view(-1), self.send[b].view(-1), group=self.group, async_op=True)
+        self.slot, self.k = (self.slot + 1) % self.depth, 0
+
+    def submit(self, stream=None):
+        b = self.slot
+        with self._on(stream):
+            if self.cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.send[b].device))
+                self.rendered[b].append(ev)
+            self.k += 1
+            if self.k == self.world:
+                self._exchange(b)
+        out, self.done = self.done, None
+        return out
+
+    def drain(self, stream=None):
+        with self._on(stream):
+            if self.k > 0:
+                self._exchange(self.slot)
+            out = [self._finish((self.slot + i) % self.depth) for i in range(self.depth)]
+        first, self.done = self.done, None
+        return [x for x in [first] + out if x is not None]

@@ -738,6 +738,24 @@ def test_raytrace_scene_writes_the_reference_ppm(tmp_path):
     assert a[:4] == ["P3", "64", "64", "255"] and len(a) == len(b) == 4 + 64 * 64 * 3
     diff = np.abs(np.array(a[4:], int) - np.array(b[4:], int))
     assert diff.max() <= 1  # a last-bit colour difference can cross an integer boundary of 255*c
+    # raytraceScene fetches the frame as the file's 8-bit pixels (rtamd_render_ppm): the text is what the float writer makes of
+    # the float framebuffer of the same frame, byte for byte
+    got = fly.render()
+    R.flyscene.write_ppm(str(tmp_path / "floats.ppm"), got["rgb"])
+    assert out.read_bytes() == (tmp_path / "floats.ppm").read_bytes()
+    pixels = np.zeros((64, 64, 3), np.uint8)
+    exact = C.c_int32(-1)
+    L.check(L.lib().rtamd_render_ppm(fly.scene, C.byref(fly.getCamera()), C.byref(fly.params), pixels.ctypes.data_as(C.c_void_p), C.byref(exact), None), "rtamd_render_ppm")
+    assert exact.value == 1
+    assert np.array_equal(pixels, np.minimum(255, (np.float32(255) * got["rgb"]).astype(np.int32)).astype(np.uint8))
+    # a channel the bytes cannot express (the reference prints a negative number): the frame is fetched as floats instead
+    fly.set_params(background=(-0.5, 0.25, 2.0))
+    fly.raytraceScene()
+    neg = fly.render()
+    R.flyscene.write_ppm(str(tmp_path / "neg.ppm"), neg["rgb"])
+    assert out.read_bytes() == (tmp_path / "neg.ppm").read_bytes() and b"-127 63 255 " in out.read_bytes()
+    L.check(L.lib().rtamd_render_ppm(fly.scene, C.byref(fly.getCamera()), C.byref(fly.params), pixels.ctypes.data_as(C.c_void_p), C.byref(exact), None), "rtamd_render_ppm")
+    assert exact.value == 0
 
 
 # ---- the benchmark configurations at full size: properties that do not need the oracle on every pixel

@@ -143,3 +143,77 @@ def test_pipeline_single_process(depth, frames):
             out.append(img)
     out += pipe.drain()
     assert [float(x[0, 0, 0]) for x in out] == [float(k) for k in range(frames)]
+
+
+def _frames_worker(rank, world, port, width, height, tile, frames, q, kind, dtype, depth):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        base = R.default_params(width, height, row_tile=tile)
+        mine = tiles.part_params(base, world, rank)
+        lib = L.lib()
+        rows = lib.rtamd_local_rows(C.byref(mine))
+        if kind == "rotate":
+            pipe = tiles.GatherPipeline(mine, width, 3, "cpu", dtype=dtype, depth=depth, rotate=True)
+        else:
+            pipe = tiles.AllToAllPipeline(mine, width, 3, "cpu", dtype=dtype, depth=depth)
+        got = []
+        for k in range(frames):
+            buf = pipe.acquire()
+            for lr in range(rows):
+                buf[lr, :, 0] = lib.rtamd_global_row(C.byref(mine), lr)
+                buf[lr, :, 1] = k
+                buf[lr, :, 2] = rank
+            img = pipe.submit()
+            if img is not None:
+                got.append(img.numpy().copy())
+        got += [x.numpy().copy() for x in pipe.drain()]
+        q.put((rank, got))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,world,height,tile,frames,dtype,depth", [
+    ("rotate", 2, 37, 8, 5, torch.float32, 2), ("rotate", 3, 50, 4, 7, torch.float32, 4), ("rotate", 2, 21, 4, 3, torch.uint8, 8),
+    ("all_to_all", 2, 37, 8, 6, torch.float32, 2), ("all_to_all", 3, 50, 4, 7, torch.float32, 2), ("all_to_all", 3, 16, 16, 1, torch.float32, 2),
+    ("all_to_all", 2, 37, 8, 11, torch.uint8, 3), ("all_to_all", 3, 21, 4, 9, torch.float32, 8)])
+def test_frames_delivered_on_rotating_roots(kind, world, height, tile, frames, dtype, depth):
+    """Frame k whole on rank k % world, every rank's frames in order: by one gather per frame with a rotating root, or by
+    one all-to-all per batch of `world` frames (a last batch may be partial)."""
+    width = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_frames_worker, args=(r, world, port, width, height, tile, frames, q, kind, dtype, depth)) for r in range(world)]
+    for p in procs:
+        p.start()
+    per_rank = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ys = np.arange(height, dtype=np.float32)
+    for r in range(world):
+        want = list(range(r, frames, world))
+        assert [int(img[0, 0, 1]) for img in per_rank[r]] == want, (r, want)
+        for img in per_rank[r]:
+            assert img.shape == (height, width, 3)
+            assert np.array_equal(img[:, 0, 0], ys)
+            assert (img[:, :, 1] == img[0, 0, 1]).all()
+            assert np.array_equal(img[:, 0, 2], ((ys // tile) % world).astype(np.float32))
+
+
+@pytest.mark.parametrize("depth,frames", [(2, 3), (3, 7)])
+def test_all_to_all_pipeline_single_process(depth, frames):
+    p = R.default_params(4, 6)
+    pipe = tiles.AllToAllPipeline(p, 4, 3, "cpu", depth=depth)
+    out = []
+    for k in range(frames):
+        buf = pipe.acquire()
+        buf.fill_(k)
+        img = pipe.submit()
+        if img is not None:
+            out.append(img.clone())
+    out += pipe.drain()
+    assert [float(x[0, 0, 0]) for x in out] == [float(k) for k in range(frames)]
