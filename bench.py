@@ -80,7 +80,10 @@ def parse():
     ap.add_argument("--size", default=None, help="WxH: render the workload at another image size (experiments; the line names it)")
     ap.add_argument("--soft-points", type=int, default=None, help="experiments: soft-shadow samples per light instead of the workload's (the line names it)")
     ap.add_argument("--max-reflections", type=int, default=None, help="experiments: bounce depth instead of the workload's (the line names it)")
-    ap.add_argument("--row-tile", type=int, default=16)
+    ap.add_argument("--row-tile", type=int, default=0,
+                    help="rows per tile of the partition over GPUs; 0 = about six tiles per GPU (height / (6 N), at least 16): coarse enough "
+                         "that a rank drops most faces of other ranks' rows unseen, fine enough to balance the ranks (1.1 M-face field at "
+                         "4K, slowest of eight ranks: 0.0545 ms per frame with tiles of 45 rows, 0.0576 with 16, 0.0602 with 135)")
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH: faces per leaf (0 = library default)")
     ap.add_argument("--sah-bins", type=int, default=0, help="BVH: SAH bins (0 = library default)")
     ap.add_argument("--in-flight", type=int, default=0,
@@ -284,6 +287,8 @@ def main():
     init_s = time.time() - t0
     W, H = w["width"], w["height"]
 
+    if a.row_tile <= 0:
+        a.row_tile = 16 if world == 1 else max(16, H // (6 * world))
     base = fly.params_copy(row_tile=a.row_tile)
     mine = tiles.part_params(base, world, rank)
     rows = fly.local_rows(mine)

@@ -131,6 +131,7 @@ struct Workspace {
     unsigned long long *pix_key;
     int32_t *tile_flag;       // face pass: per 8x8 tile of the local image, set when a face was accepted for one of its pixels
     int32_t prefilled;        // the output planes already hold what a primary miss leaves (prep_kernel): misses write nothing
+    int32_t prefill_with_faces; // ... written by extra workgroups of the face pass's launch instead of by prep_kernel
     // screen binning of the primary rays; bin_entries == nullptr: not in use
     BinState *bin_state;
     int32_t *bin_count;   // per bin: faces whose projection touches it; then the fill cursor

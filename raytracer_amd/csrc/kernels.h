@@ -14,7 +14,9 @@ namespace rtamd {
 void launch_prep(const FrameConst &fc, const Workspace &ws, void *zero, size_t zero_bytes, void *zero_b, size_t zero_b_bytes, float *rgb,
                  int32_t *face_id, float *t_hit, hipStream_t stream);
 // Primary rays of one pass resolved face by face into ws.pix_key (zeroed by launch_prep); launch_compact reads it.
-void launch_primary_faces(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, hipStream_t stream);
+// With ws.prefilled and ws.prefill_with_faces the launch also writes the miss values into the output planes (extra workgroups).
+void launch_primary_faces(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, float *rgb, int32_t *face_id,
+                          float *t_hit, hipStream_t stream);
 // Screen binning of the primary rays of one pass (ws.bin_entries must be set): count, claim, fill, test.
 void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, bool cleared,
                          hipStream_t stream);

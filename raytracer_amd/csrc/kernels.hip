@@ -275,7 +275,10 @@ constexpr int kMinGroupShift = RT_MIN_GROUP_SHIFT; // narrowest group: 16 rays
 #define RT_SHADOW_SPLIT_SHIFT 4
 #endif
 constexpr int kSplitRaysBelow = RT_SPLIT_RAYS_BELOW;           // bounce launches below this many rays put several lanes on a ray
-constexpr int kFullChipWaves = 8192;               // a launch with fewer groups leaves SIMDs of the 256 CUs idle
+#ifndef RT_FULL_CHIP_WAVES
+#define RT_FULL_CHIP_WAVES 8192
+#endif
+constexpr int kFullChipWaves = RT_FULL_CHIP_WAVES; // a launch with fewer groups leaves SIMDs of the 256 CUs idle
 
 // Orders this wave's LDS traffic against its own later LDS traffic (the hardware keeps a wave's LDS operations in
 // order; this keeps the compiler from moving them).
@@ -1375,11 +1378,46 @@ __device__ __forceinline__ void raster_pairs(const FrameConst &fc, const Workspa
     }
 }
 
+// What a primary ray that hits nothing leaves in the output planes (background colour, RTAMD_FACE_MISS, distance 0:
+// src/flyscene.cpp:650-658), written into EVERY pixel in whole coalesced lines by threads i, i + stride, ...
+__device__ __forceinline__ void prefill_planes(const FrameConst &fc, float *rgb, int32_t *face_id, float *t_hit, int i, int stride) {
+    const int pixels = fc.local_rows * fc.width;
+    // four floats a store where the plane allows it: float 4 k + e holds channel (k + e) mod 3
+    // (selected component by component: a choice between whole float4 values is lowered to an array in scratch memory)
+    const int quads = ((uintptr_t)rgb & 15) == 0 ? (3 * pixels) >> 2 : 0;
+    const float b0 = fc.bg[0], b1 = fc.bg[1], b2 = fc.bg[2];
+    for (int k = i; k < quads; k += stride) {
+        const int m = k - (k / 3) * 3;
+        float4 v;
+        v.x = m == 0 ? b0 : m == 1 ? b1 : b2;
+        v.y = m == 0 ? b1 : m == 1 ? b2 : b0;
+        v.z = m == 0 ? b2 : m == 1 ? b0 : b1;
+        v.w = v.x;
+        ((float4 *)rgb)[k] = v;
+    }
+    for (int k = 4 * quads + i; k < 3 * pixels; k += stride) {
+        const int c = k - (k / 3) * 3;
+        rgb[k] = c == 0 ? fc.bg[0] : c == 1 ? fc.bg[1] : fc.bg[2];
+    }
+    if (face_id)
+        for (int k = i; k < pixels; k += stride) face_id[k] = -2;
+    if (t_hit)
+        for (int k = i; k < pixels; k += stride) t_hit[k] = 0.0f;
+}
+
 template <bool COUNT>
 // `fshift`: a wave takes 1 << fshift faces (6: one per lane).  A mesh of few faces makes few waves -- 69 K faces are 1085
 // waves of 64, a seventh of what the chip holds, each with hundreds of pairs to step through one batch after the other -- so
 // the launcher gives a wave fewer faces then (launch_primary_faces); their pairs are dealt over all 64 lanes either way.
-__global__ __launch_bounds__(256) void face_raster_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int num_tris, int fshift) {
+// Workgroups from `raster_blocks` on do not look at faces: they write the miss values into the output planes (ws.prefill_with_faces:
+// the sweep that prep_kernel otherwise makes, which nothing in this kernel depends on -- a launch of its own costs a frame that
+// is alone on the GPU its duration and a kernel boundary).
+__global__ __launch_bounds__(256) void face_raster_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int num_tris, int fshift, int raster_blocks, float *rgb,
+                                                         int32_t *face_id, float *t_hit) {
+    if ((int)blockIdx.x >= raster_blocks) {
+        prefill_planes(fc, rgb, face_id, t_hit, ((int)blockIdx.x - raster_blocks) * 256 + (int)threadIdx.x, ((int)gridDim.x - raster_blocks) * 256);
+        return;
+    }
     __shared__ float4 s_rec[4][4][64]; // per wave: the four quarters of its faces' records
     __shared__ int4 s_box[4][64];      // ... first pixel column and row, box width, floor(2^32 / width)
     __shared__ int s_off[4][64];       // ... number of the face's first pair
@@ -2220,30 +2258,7 @@ __global__ __launch_bounds__(256) void shade_compact_kernel(DeviceScene sc, Fram
 __global__ __launch_bounds__(256) void prep_kernel(FrameConst fc, Workspace ws, int4 *zero, int zero16, int4 *zero_b, int zero_b16, float *rgb,
                                                    int32_t *face_id, float *t_hit) {
     const int i = (int)(blockIdx.x * 256 + threadIdx.x);
-    if (ws.prefilled) {
-        const int pixels = fc.local_rows * fc.width, stride = (int)gridDim.x * 256;
-        // four floats a store where the plane allows it: float 4 k + e holds channel (k + e) mod 3
-        // (selected component by component: a choice between whole float4 values is lowered to an array in scratch memory)
-        const int quads = ((uintptr_t)rgb & 15) == 0 ? (3 * pixels) >> 2 : 0;
-        const float b0 = fc.bg[0], b1 = fc.bg[1], b2 = fc.bg[2];
-        for (int k = i; k < quads; k += stride) {
-            const int m = k - (k / 3) * 3;
-            float4 v;
-            v.x = m == 0 ? b0 : m == 1 ? b1 : b2;
-            v.y = m == 0 ? b1 : m == 1 ? b2 : b0;
-            v.z = m == 0 ? b2 : m == 1 ? b0 : b1;
-            v.w = v.x;
-            ((float4 *)rgb)[k] = v;
-        }
-        for (int k = 4 * quads + i; k < 3 * pixels; k += stride) {
-            const int c = k - (k / 3) * 3;
-            rgb[k] = c == 0 ? fc.bg[0] : c == 1 ? fc.bg[1] : fc.bg[2];
-        }
-        if (face_id)
-            for (int k = i; k < pixels; k += stride) face_id[k] = -2;
-        if (t_hit)
-            for (int k = i; k < pixels; k += stride) t_hit[k] = 0.0f;
-    }
+    if (ws.prefilled && !ws.prefill_with_faces) prefill_planes(fc, rgb, face_id, t_hit, i, (int)gridDim.x * 256);
     for (int k = i; k < zero16; k += (int)gridDim.x * 256) zero[k] = make_int4(0, 0, 0, 0);
     for (int k = i; k < zero_b16; k += (int)gridDim.x * 256) zero_b[k] = make_int4(0, 0, 0, 0);
     const int nx = fc.tiles_x * 8, ny = fc.tiles_y * 8;
@@ -2351,15 +2366,17 @@ void launch_prep(const FrameConst &fc, const Workspace &ws, void *zero, size_t z
                  int32_t *face_id, float *t_hit, hipStream_t stream) {
     const int zero16 = (int)((zero_bytes + 15) / 16), zero_b16 = (int)((zero_b_bytes + 15) / 16);
     int items = std::max(std::max(zero16, zero_b16), (fc.tiles_x + fc.tiles_y) * 8);
-    if (ws.prefilled) items = std::max(items, (int)std::min<long long>(3ll * fc.local_rows * fc.width / 4, 1 << 30)); // four stores per thread
-    const int blocks = std::max(1, std::min(ws.prefilled ? 16384 : 2048, (items + 255) / 256));
+    const bool fills = ws.prefilled && !ws.prefill_with_faces;
+    if (fills) items = std::max(items, (int)std::min<long long>(3ll * fc.local_rows * fc.width / 4, 1 << 30)); // four stores per thread
+    const int blocks = std::max(1, std::min(fills ? 16384 : 2048, (items + 255) / 256));
     prep_kernel<<<blocks, 256, 0, stream>>>(fc, ws, (int4 *)zero, zero16, (int4 *)zero_b, zero_b16, rgb, face_id, t_hit);
 }
 
 // Primary rays of one pass face by face (ws.pix_key must be set and zeroed): one launch.  The pixels are resolved by
 // launch_compact; the tree walk behind it (launch_walk_closest) only does anything where the pass gave way to it.
-void launch_primary_faces(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, hipStream_t stream) {
-    if (num_tris <= 0) return;
+void launch_primary_faces(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, float *rgb, int32_t *face_id,
+                          float *t_hit, hipStream_t stream) {
+    if (num_tris <= 0 && !(ws.prefilled && ws.prefill_with_faces)) return;
     // Faces per wave: 64, or down to 16 while that leaves fewer than 4096 waves (the chip holds about 7000 of this kernel).
     // 69 K faces at 1080p, a frame alone: 42.6 us with 64, 34.4 with 32, 25.8 with 16, 23.1 with 8; at 4K 140 / 102 / 70 / 49.
     // With frames in flight 16 is as fast as 64 or a shade faster, 8 and 4 cost 2-7 % (idle lanes while projecting).
@@ -2368,11 +2385,14 @@ void launch_primary_faces(bool count, const DeviceScene &sc, const FrameConst &f
     while (fshift > 4 && ((long long)num_tris >> fshift) < 4096) --fshift;
     if (forced >= 2 && forced <= 6) fshift = forced;
     const unsigned per_block = 4u << fshift;
-    const unsigned blocks = (unsigned)(((unsigned)num_tris + per_block - 1) / per_block);
+    const unsigned blocks = (unsigned)(((unsigned)std::max(num_tris, 0) + per_block - 1) / per_block);
+    unsigned fill_blocks = 0; // (four stores per thread and trip, as in launch_prep)
+    if (ws.prefilled && ws.prefill_with_faces)
+        fill_blocks = (unsigned)std::max(1ll, std::min(16384ll, (3ll * fc.local_rows * fc.width / 4 + 255) / 256));
     if (count)
-        face_raster_kernel<true><<<blocks, 256, 0, stream>>>(sc, fc, ws, num_tris, fshift);
+        face_raster_kernel<true><<<blocks + fill_blocks, 256, 0, stream>>>(sc, fc, ws, num_tris, fshift, (int)blocks, rgb, face_id, t_hit);
     else
-        face_raster_kernel<false><<<blocks, 256, 0, stream>>>(sc, fc, ws, num_tris, fshift);
+        face_raster_kernel<false><<<blocks + fill_blocks, 256, 0, stream>>>(sc, fc, ws, num_tris, fshift, (int)blocks, rgb, face_id, t_hit);
 }
 
 void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, bool cleared,
@@ -2413,6 +2433,11 @@ namespace {
 long long with_margin(int expect) { return (long long)expect + (expect >> 2) + 64; }
 } // namespace
 
+// Grid of the primary tree walk behind a screen-space pass that earlier frames of the view saw accepted: the launch then only
+// finds out that it has nothing to do (it strides over the pixels should the pass have given way after all).
+#ifndef RT_FALLBACK_WALK_BLOCKS
+#define RT_FALLBACK_WALK_BLOCKS 256
+#endif
 void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int stage, int depth,
                          int expect, hipStream_t stream) {
     const int total_static = fc.tiles_x * fc.tiles_y * 64;
@@ -2421,8 +2446,8 @@ void launch_walk_closest(bool primary, bool count, const DeviceScene &sc, const 
     // lists too long to pay): a moderate grid (the kernel strides over the groups) keeps the usual early exit cheap.
     long long groups = primary ? fc.tiles_x * fc.tiles_y : ws.capacity / 64;
     if (!primary && expect >= 0) // narrow groups (a launch alone on the chip) hold as few as sixteen rays
-        groups = std::min(groups, (with_margin(expect) + (ws.full_waves ? 63 : 15)) / (ws.full_waves ? 64 : 16));
-    const int blocks = primary && (ws.bin_entries || ws.pix_key) ? (ws.bins_expected ? 2048 : 16384) : walk_grid(groups);
+        groups = std::min(groups, (with_margin(expect) + (ws.full_waves ? 63 : (1 << kMinGroupShift) - 1)) / (ws.full_waves ? 64 : 1 << kMinGroupShift));
+    const int blocks = primary && (ws.bin_entries || ws.pix_key) ? (ws.bins_expected ? RT_FALLBACK_WALK_BLOCKS : 16384) : walk_grid(groups);
     static const int steal = getenv("RTAMD_WALK_STEAL") ? atoi(getenv("RTAMD_WALK_STEAL")) : 1; // experiment hook
     if (steal && fc.t_eps > 0.0f) { // (the shared nearest distance is ordered by its bits: distances must be positive, -0.0f included)
         if (primary) {
@@ -2518,7 +2543,7 @@ void launch_shade(bool primary, const DeviceScene &sc, const FrameConst &fc, con
 namespace {
 int bounce_walk_blocks(const Workspace &ws, int expect) {
     long long groups = ws.capacity / 64;
-    if (expect >= 0) groups = std::min(groups, (with_margin(expect) + (ws.full_waves ? 63 : 15)) / (ws.full_waves ? 64 : 16));
+    if (expect >= 0) groups = std::min(groups, (with_margin(expect) + (ws.full_waves ? 63 : (1 << kMinGroupShift) - 1)) / (ws.full_waves ? 64 : 1 << kMinGroupShift));
     return walk_grid(groups);
 }
 int shadow_blocks(const DeviceScene &sc, const FrameConst &fc, int expect) {

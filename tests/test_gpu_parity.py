@@ -927,6 +927,41 @@ def test_gather_pipeline_rehearsal_on_streams():
         assert np.array_equal(img, want)
 
 
+def test_all_to_all_pipeline_rehearsal_on_streams():
+    """The same loop through the batched exchange (one process: batches of one frame, a device copy on a side stream where
+    the all-to-all would be): frames on three streams into the chunks of the send buffers, every frame back in order."""
+    import torch
+
+    from raytracer_amd import tiles
+
+    fly, _ = make_pair("NthTest", width=96, height=64)
+    p = fly.params_copy(row_tile=16)
+    pipe = tiles.AllToAllPipeline(p, 96, 3, torch.device("cuda", 0), dtype=torch.float32, depth=3, rehearse=True)
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    ref = torch.zeros((64, 96, 3), dtype=torch.float32, device="cuda")
+    fly.render_device(ref, params=p)
+    torch.cuda.synchronize()
+    want = ref.cpu().numpy()
+    got = []
+    for k in range(8):
+        s = streams[k % 3]
+        buf = pipe.acquire(s)
+        fly.render_device(buf, params=p, stream=s)
+        with torch.cuda.stream(s):
+            buf[0, 0, 0] = k  # marks the frame
+        img = pipe.submit(s)
+        if img is not None:
+            got.append(img)
+    got += pipe.drain()
+    torch.cuda.synchronize()
+    assert len(got) == 8
+    for k, img in enumerate(got):
+        img = img.cpu().numpy()
+        assert img[0, 0, 0] == k
+        img[0, 0, 0] = want[0, 0, 0]
+        assert np.array_equal(img.view(np.uint32), want.view(np.uint32))
+
+
 @pytest.mark.parametrize("seed,size", [(0, (640, 480)), (1, (1920, 1080)), (2, (333, 777))])
 def test_faces_smaller_than_a_pixel_bins_and_grids_against_the_tree(seed, size):
     """Dust: tens of thousands of faces of about a pixel and less, several per pixel.  Their projected boxes are
