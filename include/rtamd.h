@@ -154,7 +154,8 @@ typedef struct {
 typedef struct {
     /* Counters of the most recent frame. */
     uint64_t rays_primary; /* one per pixel sub-sample                                            */
-    uint64_t rays_shadow;  /* num_lights*samples_per_light per hit (src/flyscene.cpp:880-887)     */
+    uint64_t rays_shadow;  /* shadow rays shot, counted by the kernels that shoot them: one per hit, sampled light and
+                              sample point (src/flyscene.cpp:880-887)                              */
     uint64_t rays_bounce;  /* reflection rays (src/flyscene.cpp:636)                              */
     uint64_t hits;         /* closest-hit queries that found a surface                            */
     /* RTAMD_FLAG_COUNT_WORK only, most recent frame; [0] = BVH walk for closest hits (bounce rays, and
@@ -176,7 +177,8 @@ typedef struct {
     float ms_raster;       /* screen-space pass of the primary rays: the face raster kernel, or with forced bins the
                             * bin count, offsets, fill and raster kernels                          */
     int32_t launches_raster; /* passes, not kernels                                               */
-    /* Last pass of the most recent frame; the bin figures only when it binned its faces (0 otherwise): */
+    /* LAST pass (SSAA sub-sample) and last band of rows of the most recent frame -- earlier passes and bands may have gone the
+     * other way; the bin figures only when it binned its faces (0 otherwise): */
     uint32_t bin_entries;    /* face references in the screen bins                                */
     uint32_t bins_nonempty;  /* bins holding at least one face                                    */
     int32_t primary_path;    /* 1: primary rays were resolved in screen space (face by face, or through the bins),

@@ -8,16 +8,14 @@ import re
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "profiles_" + tag)
 dst = os.path.join(root, "profiles")
 for f in glob.glob(os.path.join(src, "bench_*.json")):
     shutil.copy(f, os.path.join(dst, "%s_%s" % (tag, os.path.basename(f))))
-shutil.copy(os.path.join(src, "pmc_bunny_1080p.txt"), os.path.join(dst, tag + "_pmc_bunny_1080p.txt"))
-for mode in ("serial", "default"):
-    stats = sorted(glob.glob(os.path.join(src, "trace_" + mode, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
-    shutil.copy(stats[-1], os.path.join(dst, "%s_kernel_stats_bunny_1080p_%s.csv" % (tag, mode)))
+for f in glob.glob(os.path.join(src, "pmc_*.txt")) + glob.glob(os.path.join(src, "kernel_stats_*.csv")):
+    shutil.copy(f, os.path.join(dst, "%s_%s" % (tag, os.path.basename(f))))
 
 
 def line(path):
@@ -37,7 +35,7 @@ d = line(os.path.join(dst, tag + "_bench_bunny_1080p.json"))
 r = d["roofline"]
 print({k: r[k] for k in ("kernel", "bound", "achieved", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "launches_per_frame", "share_of_frame")})
 print(d["roofline_valu"])
-print("cpu", d["cpu_baseline"]["value"], "host boundary", d["host_boundary"]["ms_per_frame"], d["host_boundary"]["ms_per_frame_pageable_buffers"],
+print("cpu", d["cpu_baseline"]["value"], "host boundary", d["host_boundary"],
       "single", d["single_frame"]["wall_ms"], d["single_frame"]["events_ms"])
 tv = tb = 0.0
 for name, v in d["kernels_profiled"]["per_launch"].items():
