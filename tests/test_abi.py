@@ -102,3 +102,21 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("the oracle", "").lower() or f == "workloads.py", (dirpath, f)
+
+
+def test_scene_desc_layout_and_argument_checks_of_the_light_and_ppm_entry_points():
+    # rtamd_scene_desc on LP64: num_unsampled_lights took the padding behind num_textures, so the struct kept its size and a
+    # caller that zero-fills it (as every caller of the earlier layout did) says "every light is sampled"
+    assert C.sizeof(L.SceneDesc) == 168 and L.SceneDesc.num_unsampled_lights.offset == 164
+    lib = L.lib()
+    out = C.c_void_p()
+    d = L.SceneDesc()
+    d.num_lights, d.num_unsampled_lights = 1, 2
+    assert lib.rtamd_scene_create(C.byref(d), None, C.byref(out)) == L.ERR_INVALID
+    assert b"without shadow samples" in lib.rtamd_last_error()
+    d.num_unsampled_lights = -1
+    assert lib.rtamd_scene_create(C.byref(d), None, C.byref(out)) == L.ERR_INVALID
+    assert lib.rtamd_scene_set_lights(None, None, None, 0) == L.ERR_INVALID
+    cam, p = R.default_camera(8, 8), R.default_params(8, 8)
+    pixels = (C.c_uint8 * (8 * 8 * 3))()
+    assert lib.rtamd_render_ppm(None, C.byref(cam), C.byref(p), pixels, None, None) == L.ERR_INVALID

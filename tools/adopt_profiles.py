@@ -46,4 +46,4 @@ for mode in ("serial", "default"):
         m = re.search(r"(\w+_kernel(<[^>]*>)?)", row["Name"])
         print("  %-34s %5s calls %8.1f us avg %8.1f min %8.1f max" % (m.group(1) if m else row["Name"][:34], row["Calls"], float(row["AverageNs"]) / 1e3,
                                                                        float(row["MinNs"]) / 1e3, float(row["MaxNs"]) / 1e3))
-print("under rocprof (default):", line(os.path.join(dst, tag + "_bench_under_rocprof_default.json"))["ms_per_step"])
+print("under rocprof (default):", line(os.path.join(dst, tag + "_bench_under_rocprof_default_bunny_1080p.json"))["ms_per_step"])

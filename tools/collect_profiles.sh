@@ -16,6 +16,7 @@ if [ "$WHAT" = counters ]; then
   bash tools/pmc_passes.sh gpurun_out/profiles_$TAG/pmc_$WL $WL || exit 1
   python3 tools/pmc_summary.py gpurun_out/profiles_$TAG/pmc_$WL/* > "$OUT/pmc_$WL.txt"
   cp "$OUT/pmc_$WL.txt" "$ROOT/profiles/${TAG}_pmc_$WL.txt"
+  rm -rf "$OUT/pmc_$WL" # (the raw counter tables are large; what comes back from the box is bounded)
   cd /tmp && export TMPDIR=/tmp
   export GPU_MAX_HW_QUEUES=16
   # 2. kernel trace with every kernel alone on the GPU and one kernel per launch: these averages are the ones the roofline's
@@ -27,6 +28,7 @@ if [ "$WHAT" = counters ]; then
     python3 "$ROOT/bench.py" --cpu-seconds 0 --in-flight 1 --workload $WL $STEPS > "$OUT/bench_under_rocprof_serial_$WL.json" 2> "$OUT/trace_serial_$WL.log" || exit 1
   cp "$(find "$OUT/trace_serial_$WL" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_${WL}_serial.csv"
   cp "$OUT/kernel_stats_${WL}_serial.csv" "$ROOT/profiles/${TAG}_kernel_stats_${WL}_serial.csv"
+  rm -rf "$OUT/trace_serial_$WL"
   exit 0
 fi
 cd /tmp && export TMPDIR=/tmp
@@ -36,6 +38,7 @@ export GPU_MAX_HW_QUEUES=16
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_default" -- \
   python3 "$ROOT/bench.py" --cpu-seconds 0 > "$OUT/bench_under_rocprof_default_bunny_1080p.json" 2> "$OUT/trace_default.log" || exit 1
 cp "$(find "$OUT/trace_default" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_bunny_1080p_default.csv"
+rm -rf "$OUT/trace_default"
 # 4. the driver's command, the default bench line, and the other single-GPU workloads
 cd "$ROOT"
 timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/bench_bunny_1080p_steps20.json" || exit 1
