@@ -1240,7 +1240,6 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(DeviceScene sc, FrameCons
 #define RT_CLUSTER_CULL(fc) ((fc).num_parts > 1)
 #endif
 constexpr int kHugePixels = 16384; // a face with a larger pixel box is tested pixel by pixel in the compaction kernel
-constexpr int kDirectPairs = 8;    // waves whose faces all have at most this many pixels skip the dealing
 
 // Can this part skip the 64 faces of record group `cluster` without looking at them?  Yes when the group's box lies wholly
 // in front of the eye and the rows its projection covers all belong to other parts (or none is on the screen): the
@@ -1297,33 +1296,9 @@ __device__ __forceinline__ int local_rows_below(const FrameConst &fc, int y) {
     return turn * fc.row_tile + (who > fc.part ? fc.row_tile : who == fc.part ? y - tile * fc.row_tile : 0);
 }
 
-// One (face, pixel) pair: the exact plane + three-edge test of src/flyscene.cpp:752-789 for the primary ray of the pixel in
-// column x of LOCAL row lr.
-template <bool COUNT>
-__device__ __forceinline__ void raster_pair(const FrameConst &fc, const Workspace &ws, float4 pn, float4 r0, float4 r1, float4 r2, int x, int lr,
-                                            unsigned &w_plane, unsigned &w_edge) {
-    const V3 o = mk(fc.origin[0], fc.origin[1], fc.origin[2]);
-    const V3 d = primary_direction(fc, ws, x, lr);
-    unsigned long long *const cell = ws.pix_key + ((size_t)lr * (size_t)fc.width + (size_t)x);
-    if (COUNT) ++w_plane;
-    const V3 n = mk(pn.x, pn.y, pn.z);
-    const float t = (pn.w - dot(o, n)) / dot(d, n);
-    if (!(t >= fc.t_eps && t <= FLT_MAX)) return; // also rejects NaN (see file header)
-    // what the pixel holds already (possibly a moment ago: it only ever gets nearer) spares the edge tests of faces behind it
-    const unsigned long long seen = *cell;
-    if (seen != 0ull && t > __int_as_float((int)(unsigned)(~seen >> 32))) return;
-    if (COUNT) ++w_edge;
-    const V3 v0 = mk(r0.x, r0.y, r0.z), v1 = mk(r1.x, r1.y, r1.z), v2 = mk(r2.x, r2.y, r2.z);
-    const V3 hp = o + t * d;
-    if (dot(cross(v1 - v0, hp - v0), n) < 0) return;
-    if (dot(cross(v2 - v1, hp - v1), n) < 0) return;
-    if (dot(cross(v0 - v2, hp - v2), n) < 0) return;
-    atomicMax(cell, ~hit_key(t, __float_as_int(r1.w)));
-    if (ws.prefilled) ws.tile_flag[(lr >> 3) * fc.tiles_x + (x >> 3)] = 1; // the compaction kernel then looks at flagged tiles only
-}
-
-// Several pairs of one lane side by side: the table entries of all their pixels in one round trip, then all keys in the
-// next (taken one after the other, a lane's pairs are a chain of two dependent fetches each).  Same tests, same atomics.
+// (Face, pixel) pairs: the exact plane + three-edge test of src/flyscene.cpp:752-789 for the primary ray of the pixel in column x
+// of LOCAL row lr.  Several pairs of one lane side by side: the table entries of all their pixels in one round trip, then all
+// keys in the next (taken one after the other, a lane's pairs are a chain of two dependent fetches each).
 struct FaceRec {
     float4 pn, r0, r1, r2;
 };
@@ -1405,29 +1380,117 @@ __device__ __forceinline__ void prefill_planes(const FrameConst &fc, float *rgb,
         for (int k = i; k < pixels; k += stride) t_hit[k] = 0.0f;
 }
 
+// ---------------------------------------------------------------------------------------------
+// A screen-space test in front of the exact one.  The box of a projected triangle holds about twice
+// the pixels the triangle covers, and the exact test of a (face, pixel) pair costs some 270 instructions (the pixel's
+// direction with its square root and division, the plane's division, three cross products).  Three edge functions of
+// the PROJECTED triangle, widened by the margin the boxes are widened by, tell for a dozen instructions that a pixel's
+// sample lies outside for good; the pairs that survive are collected in a queue of the wave and go through the exact test
+// 128 at a time, all lanes busy.  Only pairs the exact test would reject are dropped: same keys, same image.
+// ---------------------------------------------------------------------------------------------
+// G_k(x', y') = a_k x' + b_k y' + c_k for pixel (first column + x', first row + y') of the face's box: negative for some
+// k = the sample lies outside the projected triangle by more than the margin.  E(r) = dx (r.y - ey) - dy (r.x - ex) is
+// >= 0 left of the edge from e along (dx, dy); a point within the margin (in x and in y) of the triangle has
+// E >= -margin (|dx| + |dy|) for all three edges.  The margin is the one of the boxes (four times the worst error of a
+// projected corner plus the rounding of the exact test, see RT_BIN_MARGIN); a quarter more covers the rounding of G itself
+// (coordinates below 2^14 and box-relative pixels: at most a sixth of the margin term).  A face whose orientation on the
+// screen is not certain from its rounded area, or with a corner far off the screen, keeps all pixels of its box.
+struct EdgeFilter {
+    float a[3], b[3], c[3];
+};
+__device__ __forceinline__ EdgeFilter edge_filter(const FrameConst &fc, const ProjectedFace &f) {
+    EdgeFilter e;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) e.a[k] = 0.0f, e.b[k] = 0.0f, e.c[k] = 1.0f;
+    if (f.empty || f.unbounded) return e;
+    const float lim = 16384.0f;
+    const bool near_screen = fabsf(f.x0) < lim && fabsf(f.y0) < lim && fabsf(f.x1) < lim && fabsf(f.y1) < lim && fabsf(f.x2) < lim && fabsf(f.y2) < lim;
+    const float ux = f.x1 - f.x0, uy = f.y1 - f.y0, vx = f.x2 - f.x0, vy = f.y2 - f.y0;
+    const float area = ux * vy - uy * vx;
+    const float area_slop = 1e-3f + 4e-6f * (fabsf(ux * vy) + fabsf(uy * vx)); // (sixteen times the rounding of the expression above)
+    if (!near_screen || !(fabsf(area) > area_slop)) return e;
+    // corners relative to the sample of the box's first pixel
+    const float ox = (float)f.px0 + fc.sub_x, oy = (float)f.py0 + fc.sub_y;
+    const float px[3] = {f.x0 - ox, f.x1 - ox, f.x2 - ox}, py[3] = {f.y0 - oy, f.y1 - oy, f.y2 - oy};
+    const float margin = 1.25f * fc.raster_margin;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int n = k == 2 ? 0 : k + 1;
+        // counter-clockwise (area > 0): inside is left of p_k -> p_n; clockwise: left of p_n -> p_k
+        const int from = area > 0.0f ? k : n, to = area > 0.0f ? n : k;
+        const float dx = px[to] - px[from], dy = py[to] - py[from];
+        e.a[k] = -dy, e.b[k] = dx;
+        e.c[k] = (dy * px[from] - dx * py[from]) + margin * (fabsf(dx) + fabsf(dy));
+    }
+    return e;
+}
+
+#ifndef RT_FILTER_PAIRS
+#define RT_FILTER_PAIRS 2
+#endif
+// (a step adds at most 64 RT_FILTER_PAIRS entries to fewer than 64 RT_RASTER_PAIRS waiting ones)
+constexpr int kFilterRing = 64 * (RT_FILTER_PAIRS + RT_RASTER_PAIRS) <= 256 ? 256 : 512;
+static_assert(64 * (RT_FILTER_PAIRS + RT_RASTER_PAIRS) <= kFilterRing, "ring too small");
+struct RasterWaveLds {
+    float4 rec[4][64]; // the four quarters of the wave's face records
+    int4 box[64];      // first column | first LOCAL row << 16, box width | first IMAGE row << 16, floor(2^32 / width), number of the face's first pair
+    float edge[9][64]; // EdgeFilter
+    int first[64];     // number of the face's first pair again, densely (the search reads nothing else)
+    int queue[kFilterRing]; // ring of pairs that passed the screen-space test: face (6 bits) | number of the pixel in its box << 6
+};
+
+// the exact test for `n` <= 64 RT_RASTER_PAIRS pairs of the queue, starting at ring position `head`
 template <bool COUNT>
+__device__ __forceinline__ void raster_queued(const FrameConst &fc, const Workspace &ws, const RasterWaveLds &s, int head, int n, int lane, unsigned &w_plane,
+                                              unsigned &w_edge) {
+    FaceRec rec[RT_RASTER_PAIRS];
+    int px[RT_RASTER_PAIRS], pr[RT_RASTER_PAIRS];
+    bool on[RT_RASTER_PAIRS];
+#pragma unroll
+    for (int u = 0; u < RT_RASTER_PAIRS; ++u) {
+        const int at = 64 * u + lane;
+        on[u] = at < n;
+        const int e = s.queue[(head + (on[u] ? at : 0)) & (kFilterRing - 1)];
+        const int lo = e & 63;
+        const unsigned k = (unsigned)e >> 6;
+        const int4 box = s.box[lo];
+        const unsigned w = (unsigned)box.y & 0xffffu;
+        const unsigned row = fast_div(k, w, (unsigned)box.z);
+        px[u] = (box.x & 0xffff) + (int)(k - row * w), pr[u] = (int)((unsigned)box.x >> 16) + (int)row;
+        rec[u].pn = s.rec[0][lo], rec[u].r0 = s.rec[1][lo], rec[u].r1 = s.rec[2][lo], rec[u].r2 = s.rec[3][lo];
+    }
+    raster_pairs<COUNT, RT_RASTER_PAIRS>(fc, ws, rec, px, pr, on, w_plane, w_edge);
+}
+
+#ifndef RT_FILTER_WAVES
+#define RT_FILTER_WAVES 1
+#endif
+// Waves per workgroup: one (1.1 M faces at 4K: 88.9 us; two 91.0, four 95.1 -- a workgroup leaves when its slowest wave does).
+constexpr int kFilterWaves = RT_FILTER_WAVES;
 // `fshift`: a wave takes 1 << fshift faces (6: one per lane).  A mesh of few faces makes few waves -- 69 K faces are 1085
 // waves of 64, a seventh of what the chip holds, each with hundreds of pairs to step through one batch after the other -- so
 // the launcher gives a wave fewer faces then (launch_primary_faces); their pairs are dealt over all 64 lanes either way.
 // Workgroups from `raster_blocks` on do not look at faces: they write the miss values into the output planes (ws.prefill_with_faces:
 // the sweep that prep_kernel otherwise makes, which nothing in this kernel depends on -- a launch of its own costs a frame that
 // is alone on the GPU its duration and a kernel boundary).
-__global__ __launch_bounds__(256) void face_raster_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int num_tris, int fshift, int raster_blocks, float *rgb,
+template <bool COUNT>
+__global__ __launch_bounds__(64 * kFilterWaves) void face_raster_kernel(DeviceScene sc, FrameConst fc, Workspace ws, int num_tris, int fshift, int raster_blocks, float *rgb,
                                                          int32_t *face_id, float *t_hit) {
     if ((int)blockIdx.x >= raster_blocks) {
-        prefill_planes(fc, rgb, face_id, t_hit, ((int)blockIdx.x - raster_blocks) * 256 + (int)threadIdx.x, ((int)gridDim.x - raster_blocks) * 256);
+        prefill_planes(fc, rgb, face_id, t_hit, ((int)blockIdx.x - raster_blocks) * (64 * kFilterWaves) + (int)threadIdx.x,
+                       ((int)gridDim.x - raster_blocks) * (64 * kFilterWaves));
         return;
     }
-    __shared__ float4 s_rec[4][4][64]; // per wave: the four quarters of its faces' records
-    __shared__ int4 s_box[4][64];      // ... first pixel column and row, box width, floor(2^32 / width)
-    __shared__ int s_off[4][64];       // ... number of the face's first pair
+    __shared__ RasterWaveLds s_wave[kFilterWaves];
     const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const int wave_first = ((int)blockIdx.x * 4 + wave) << fshift;
+    RasterWaveLds &s = s_wave[wave];
+    const int wave_first = ((int)blockIdx.x * kFilterWaves + wave) << fshift;
     const int tri = wave_first + lane;
     const bool holds = lane < (1 << fshift) && tri < num_tris; // this lane holds a face
     unsigned w_box = 0, w_plane = 0, w_edge = 0;
     ProjectedFace f;
     f.empty = true, f.unbounded = false, f.px0 = f.py0 = 0, f.px1 = f.py1 = -1;
+    f.x0 = f.y0 = f.x1 = f.y1 = f.x2 = f.y2 = 0.0f;
     // a rank that renders some rows only: groups of faces that lie in other ranks' rows are dropped unseen
     // (a wave's faces lie in one group of 64 records: 1 << fshift divides 64)
     bool skip = false;
@@ -1438,7 +1501,7 @@ __global__ __launch_bounds__(256) void face_raster_kernel(DeviceScene sc, FrameC
     const bool large = f.unbounded || w * h > kHugePixels;
     // From here on the box's rows are this part's own (packed) rows: a face that spans the row tiles of several parts is
     // tested against the rows rendered here only, and one that touches none of them is dropped.
-    int row0 = f.py0;
+    int row0 = f.py0, first_row = f.py0; // (local and image row of the box's first row this part renders)
     if (!f.empty && fc.num_parts > 1) {
         row0 = local_rows_below(fc, f.py0);
         h = local_rows_below(fc, f.py1 + 1) - row0;
@@ -1450,98 +1513,80 @@ __global__ __launch_bounds__(256) void face_raster_kernel(DeviceScene sc, FrameC
         if (at < kMaxHugeFaces) ws.big[at] = make_int4(tri, f.px0 | (f.py0 << 16), f.px1 | (f.py1 << 16), 0);
     }
     const int count = (f.empty || huge) ? 0 : w * h;
-    int most = count;
-    for (int off = 32; off > 0; off >>= 1) most = max(most, __shfl_xor(most, off, 64));
-    if (most > 0) {
+    int incl = count; // inclusive scan of the counts over the wave
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const int up = __shfl_up(incl, dlt, 64);
+        if (lane >= dlt) incl += up;
+    }
+    const int total = __shfl(incl, 63, 64);
+    if (total > 0) {
         const int mine = holds ? tri : wave_first; // (lanes without a face have no pairs; any record will do)
-        const float4 pn = sc.tris[(size_t)mine * 4 + 0], r0 = sc.tris[(size_t)mine * 4 + 1];
-        const float4 r1 = sc.tris[(size_t)mine * 4 + 2], r2 = sc.tris[(size_t)mine * 4 + 3];
-        if (fshift == 6 && most <= kDirectPairs) {
-            // every lane its own face: k-th pixel of the box, row by row
-            int x = f.px0, y = row0;
-#if RT_RASTER_PAIRS > 1
-            FaceRec rec[RT_RASTER_PAIRS]; // (RT_RASTER_PAIRS pixels of the lane's own face per trip)
+        s.rec[0][lane] = sc.tris[(size_t)mine * 4 + 0], s.rec[1][lane] = sc.tris[(size_t)mine * 4 + 1];
+        s.rec[2][lane] = sc.tris[(size_t)mine * 4 + 2], s.rec[3][lane] = sc.tris[(size_t)mine * 4 + 3];
+        s.box[lane] = make_int4(f.px0 | (row0 << 16), max(w, 1) | (first_row << 16), (int)(w <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / (unsigned long long)w)),
+                                incl - count);
+        s.first[lane] = incl - count;
+        const EdgeFilter ef = edge_filter(fc, f);
 #pragma unroll
-            for (int u = 0; u < RT_RASTER_PAIRS; ++u) rec[u].pn = pn, rec[u].r0 = r0, rec[u].r1 = r1, rec[u].r2 = r2;
-            for (int k = 0; k < most; k += RT_RASTER_PAIRS) {
-                int px[RT_RASTER_PAIRS], pr[RT_RASTER_PAIRS];
-                bool on[RT_RASTER_PAIRS];
+        for (int k = 0; k < 3; ++k) s.edge[k][lane] = ef.a[k], s.edge[3 + k][lane] = ef.b[k], s.edge[6 + k][lane] = ef.c[k];
+        wave_sync();
+        int head = 0, tail = 0; // ring positions (the wave's own: the same in all lanes)
+        // RT_FILTER_PAIRS pairs per lane and step: their searches are independent chains of LDS reads that overlap
+        for (int j0 = 0; j0 < total; j0 += 64 * RT_FILTER_PAIRS) {
+            int lo[RT_FILTER_PAIRS], hi[RT_FILTER_PAIRS], jc[RT_FILTER_PAIRS];
+            bool pass[RT_FILTER_PAIRS];
 #pragma unroll
-                for (int u = 0; u < RT_RASTER_PAIRS; ++u) {
-                    px[u] = x, pr[u] = y, on[u] = k + u < count;
-                    if (++x > f.px1) x = f.px0, ++y;
+            for (int u = 0; u < RT_FILTER_PAIRS; ++u) {
+                const int j = j0 + 64 * u + lane;
+                pass[u] = j < total;
+                jc[u] = pass[u] ? j : 0;
+                lo[u] = 0, hi[u] = 63;
+            }
+            // the face of pair j: the last one whose first pair is <= j (faces without pixels share their successor's number)
+#pragma unroll
+            for (int step = 0; step < 6; ++step) {
+                int first[RT_FILTER_PAIRS], mid[RT_FILTER_PAIRS];
+#pragma unroll
+                for (int u = 0; u < RT_FILTER_PAIRS; ++u) mid[u] = (lo[u] + hi[u] + 1) >> 1, first[u] = s.first[mid[u]];
+#pragma unroll
+                for (int u = 0; u < RT_FILTER_PAIRS; ++u) {
+                    if (first[u] <= jc[u])
+                        lo[u] = mid[u];
+                    else
+                        hi[u] = mid[u] - 1;
                 }
-                raster_pairs<COUNT, RT_RASTER_PAIRS>(fc, ws, rec, px, pr, on, w_plane, w_edge);
             }
-#else
-            for (int k = 0; k < most; ++k) {
-                if (k < count) raster_pair<COUNT>(fc, ws, pn, r0, r1, r2, x, y, w_plane, w_edge);
-                if (++x > f.px1) x = f.px0, ++y;
+            int entry[RT_FILTER_PAIRS];
+#pragma unroll
+            for (int u = 0; u < RT_FILTER_PAIRS; ++u) {
+                const int4 box = s.box[lo[u]];
+                const unsigned k = (unsigned)(jc[u] - box.w), bw = (unsigned)box.y & 0xffffu;
+                const unsigned row = fast_div(k, bw, (unsigned)box.z);
+                const float xr = (float)(k - row * bw);
+                // rows of the box in the IMAGE: under a partition the part's rows are not consecutive there
+                const int local_row = (int)((unsigned)box.x >> 16) + (int)row;
+                const int image_row = fc.num_parts == 1 ? local_row : global_row(fc, local_row);
+                const float yr = (float)(image_row - (int)((unsigned)box.y >> 16));
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const float g = __builtin_fmaf(s.edge[e][lo[u]], xr, __builtin_fmaf(s.edge[3 + e][lo[u]], yr, s.edge[6 + e][lo[u]]));
+                    pass[u] = pass[u] && !(g < 0.0f);
+                }
+                entry[u] = lo[u] | (int)(k << 6);
             }
-#endif
-        } else {
-            s_rec[wave][0][lane] = pn, s_rec[wave][1][lane] = r0, s_rec[wave][2][lane] = r1, s_rec[wave][3][lane] = r2;
-            s_box[wave][lane] = make_int4(f.px0, row0, max(w, 1), (int)(w <= 1 ? 0xffffffffu : (unsigned)(0x100000000ull / (unsigned long long)w)));
-            int incl = count; // inclusive scan of the counts over the wave
-            for (int dlt = 1; dlt < 64; dlt <<= 1) {
-                const int up = __shfl_up(incl, dlt, 64);
-                if (lane >= dlt) incl += up;
+#pragma unroll
+            for (int u = 0; u < RT_FILTER_PAIRS; ++u) {
+                const unsigned long long passed = __ballot(pass[u]);
+                if (pass[u]) s.queue[(tail + (int)__popcll(passed & ((1ull << lane) - 1ull))) & (kFilterRing - 1)] = entry[u];
+                tail += (int)__popcll(passed);
             }
-            const int total = __shfl(incl, 63, 64);
-            s_off[wave][lane] = incl - count;
             wave_sync();
-#if RT_RASTER_PAIRS > 1
-            for (int j0 = 0; j0 < total; j0 += 64 * RT_RASTER_PAIRS) {
-                // several pairs per lane and trip: pairs j0 + lane, j0 + 64 + lane, ...
-                FaceRec rec[RT_RASTER_PAIRS];
-                int px[RT_RASTER_PAIRS], pr[RT_RASTER_PAIRS];
-                bool on[RT_RASTER_PAIRS];
-#pragma unroll
-                for (int u = 0; u < RT_RASTER_PAIRS; ++u) {
-                    const int j = j0 + 64 * u + lane;
-                    on[u] = j < total;
-                    const int jc = on[u] ? j : 0;
-                    // the face of pair j: the last one whose first pair is <= j (faces without pixels share their successor's number)
-                    int lo = 0, hi = 63;
-#pragma unroll
-                    for (int step = 0; step < 6; ++step) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (s_off[wave][mid] <= jc)
-                            lo = mid;
-                        else
-                            hi = mid - 1;
-                    }
-                    const int4 box = s_box[wave][lo];
-                    const unsigned k = (unsigned)(jc - s_off[wave][lo]);
-                    const unsigned row = fast_div(k, (unsigned)box.z, (unsigned)box.w);
-                    px[u] = box.x + (int)(k - row * (unsigned)box.z), pr[u] = box.y + (int)row;
-                    rec[u].pn = s_rec[wave][0][lo], rec[u].r0 = s_rec[wave][1][lo], rec[u].r1 = s_rec[wave][2][lo], rec[u].r2 = s_rec[wave][3][lo];
-                }
-                raster_pairs<COUNT, RT_RASTER_PAIRS>(fc, ws, rec, px, pr, on, w_plane, w_edge);
+            while (tail - head >= 64 * RT_RASTER_PAIRS) {
+                raster_queued<COUNT>(fc, ws, s, head, 64 * RT_RASTER_PAIRS, lane, w_plane, w_edge);
+                head += 64 * RT_RASTER_PAIRS;
             }
-#else
-            for (int j0 = 0; j0 < total; j0 += 64) {
-                const int j = j0 + lane;
-                if (j < total) {
-                    // the face of pair j: the last one whose first pair is <= j (faces without pixels share their successor's number)
-                    int lo = 0, hi = 63;
-#pragma unroll
-                    for (int step = 0; step < 6; ++step) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (s_off[wave][mid] <= j)
-                            lo = mid;
-                        else
-                            hi = mid - 1;
-                    }
-                    const int4 box = s_box[wave][lo];
-                    const unsigned k = (unsigned)(j - s_off[wave][lo]);
-                    const unsigned row = fast_div(k, (unsigned)box.z, (unsigned)box.w);
-                    raster_pair<COUNT>(fc, ws, s_rec[wave][0][lo], s_rec[wave][1][lo], s_rec[wave][2][lo], s_rec[wave][3][lo], box.x + (int)(k - row * (unsigned)box.z),
-                                       box.y + (int)row, w_plane, w_edge);
-                }
-            }
-#endif
         }
+        if (tail > head) raster_queued<COUNT>(fc, ws, s, head, tail - head, lane, w_plane, w_edge);
     }
     if (COUNT) flush_work(w_box, w_plane, w_edge, ws.work + 2);
 }
@@ -2377,22 +2422,25 @@ void launch_prep(const FrameConst &fc, const Workspace &ws, void *zero, size_t z
 void launch_primary_faces(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, float *rgb, int32_t *face_id,
                           float *t_hit, hipStream_t stream) {
     if (num_tris <= 0 && !(ws.prefilled && ws.prefill_with_faces)) return;
-    // Faces per wave: 64, or down to 16 while that leaves fewer than 4096 waves (the chip holds about 7000 of this kernel).
-    // 69 K faces at 1080p, a frame alone: 42.6 us with 64, 34.4 with 32, 25.8 with 16, 23.1 with 8; at 4K 140 / 102 / 70 / 49.
-    // With frames in flight 16 is as fast as 64 or a shade faster, 8 and 4 cost 2-7 % (idle lanes while projecting).
+    // Faces per wave: 64, or fewer while that leaves fewer than 4096 waves (the chip holds about 5000 of this kernel): down to 16 for
+    // a frame alone on the GPU, whose few waves would each step through hundreds of pairs one batch after the other; down to 32
+    // with frames in flight, which fill the chip between them and pay for every wave's projection with its idle lanes.
+    // 69 K faces, frames in flight, ms per frame with 16 / 32 / 64 faces per wave: 0.0940 / 0.0922 / 0.0920 at 1080p, 0.0886 /
+    // 0.0875 / 0.0869 at 4K; a frame alone: 0.179 / 0.181 / 0.187 and 0.142 / 0.156 / 0.184.
     static const int forced = getenv("RTAMD_RASTER_FACES_PER_WAVE_SHIFT") ? atoi(getenv("RTAMD_RASTER_FACES_PER_WAVE_SHIFT")) : -1; // experiment hook
     int fshift = 6;
-    while (fshift > 4 && ((long long)num_tris >> fshift) < 4096) --fshift;
+    const int fewest = ws.full_waves ? 5 : 4;
+    while (fshift > fewest && ((long long)num_tris >> fshift) < 4096) --fshift;
     if (forced >= 2 && forced <= 6) fshift = forced;
-    const unsigned per_block = 4u << fshift;
+    const unsigned threads = 64u * (unsigned)kFilterWaves, per_block = (unsigned)kFilterWaves << fshift;
     const unsigned blocks = (unsigned)(((unsigned)std::max(num_tris, 0) + per_block - 1) / per_block);
     unsigned fill_blocks = 0; // (four stores per thread and trip, as in launch_prep)
     if (ws.prefilled && ws.prefill_with_faces)
-        fill_blocks = (unsigned)std::max(1ll, std::min(16384ll, (3ll * fc.local_rows * fc.width / 4 + 255) / 256));
+        fill_blocks = (unsigned)std::max(1ll, std::min(4194304ll / threads, (3ll * fc.local_rows * fc.width / 4 + threads - 1) / threads));
     if (count)
-        face_raster_kernel<true><<<blocks + fill_blocks, 256, 0, stream>>>(sc, fc, ws, num_tris, fshift, (int)blocks, rgb, face_id, t_hit);
+        face_raster_kernel<true><<<blocks + fill_blocks, threads, 0, stream>>>(sc, fc, ws, num_tris, fshift, (int)blocks, rgb, face_id, t_hit);
     else
-        face_raster_kernel<false><<<blocks + fill_blocks, 256, 0, stream>>>(sc, fc, ws, num_tris, fshift, (int)blocks, rgb, face_id, t_hit);
+        face_raster_kernel<false><<<blocks + fill_blocks, threads, 0, stream>>>(sc, fc, ws, num_tris, fshift, (int)blocks, rgb, face_id, t_hit);
 }
 
 void launch_primary_bins(bool count, const DeviceScene &sc, const FrameConst &fc, const Workspace &ws, int num_tris, bool cleared,

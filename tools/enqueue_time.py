@@ -1,4 +1,4 @@
-"""Host time to enqueue a frame vs GPU time per frame: python tools/enqueue_time.py WORKLOAD [IN_FLIGHT [WORLD]]
+"""Host time to enqueue a frame vs GPU time per frame: python tools/enqueue_time.py WORKLOAD [IN_FLIGHT [WORLD [ROW_TILE]]]
 (WORLD > 1: rank 0's share of a frame partitioned over WORLD ranks)"""
 import sys
 import time
@@ -14,7 +14,8 @@ world = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 w = workloads.get(name)
 fly, params, cam = workloads.make_flyscene(w)
 streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(F - 1)]
-p = tiles.part_params(fly.params_copy(row_tile=16), world, 0) if world > 1 else fly.params_copy()
+row_tile = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+p = tiles.part_params(fly.params_copy(row_tile=row_tile), world, 0) if world > 1 else fly.params_copy()
 rows = fly.local_rows(p) if world > 1 else w["height"]
 bufs = [torch.zeros((rows, w["width"], 3), dtype=torch.float32, device="cuda") for _ in range(F)]
 for n in (20, 200):
