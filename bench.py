@@ -83,7 +83,8 @@ def parse():
     ap.add_argument("--row-tile", type=int, default=0,
                     help="rows per tile of the partition over GPUs; 0 = about six tiles per GPU (height / (6 N), at least 16): coarse enough "
                          "that a rank drops most faces of other ranks' rows unseen, fine enough to balance the ranks (1.1 M-face field at "
-                         "4K, slowest of eight ranks: 0.0545 ms per frame with tiles of 45 rows, 0.0576 with 16, 0.0602 with 135)")
+                         "4K, slowest of eight ranks: 0.052 ms per frame with tiles of 45 rows, 0.052 with 16, 0.060 with 135; four ranks: "
+                         "0.090 with 90 rows, 0.096 with 16)")
     ap.add_argument("--max-leaf", type=int, default=0, help="BVH: faces per leaf (0 = library default)")
     ap.add_argument("--sah-bins", type=int, default=0, help="BVH: SAH bins (0 = library default)")
     ap.add_argument("--in-flight", type=int, default=0,
