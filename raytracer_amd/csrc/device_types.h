@@ -35,6 +35,10 @@ struct DeviceScene {
     // the (up to) sixteen grandchildren of the root, where the lanes of a shared ray start (0x7fffffff: none)
     int32_t start16[16];
     int32_t num_records; // TriRecords (= planes = shading records)
+    // Slack of the tree's boxes in space: 2^-20 of the largest coordinate of any face.  The exact face test rounds, so it may accept
+    // a point a few units in the last place outside a face's own box (a ray through a corner of the face, a ray that runs IN the
+    // plane of a box side); the slab tests let a ray pass that misses a box by less than this.
+    float box_slack;
 };
 
 // Per-launch constants (camera + the reference's macros).

@@ -397,8 +397,7 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
         // infinity or NaN enters the min/max chains.  origin*inv is rounded once, which puts an ABSOLUTE error of
         // up to half an ulp of |origin*inv| on every slab distance of that axis; each axis widens its own
         // interval by one ulp (folded into the addends), so a nearly axis-parallel ray, whose products are
-        // astronomically large on one axis, still culls normally on the other two.  Clamped axes are not widened:
-        // their distances are exact zeros or astronomically large with a reliable sign.
+        // astronomically large on one axis, still culls normally on the other two.
         constexpr float kInvMax = 1e25f;
         float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
         const bool cx = !(fabsf(ix) <= kInvMax), cy = !(fabsf(iy) <= kInvMax), cz = !(fabsf(iz) <= kInvMax);
@@ -409,7 +408,10 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
         // direction, hi for a negative one); the exit bounds sit 16 bytes to the other side (offset ^ 16)
         const unsigned offx = ix < 0.0f ? 16u : 0u, offy = iy < 0.0f ? 48u : 32u, offz = iz < 0.0f ? 80u : 64u;
         const float bx = -o.x * ix, by = -o.y * iy, bz = -o.z * iz;
-        const float ex = cx ? 0.0f : 1.2e-7f * fabsf(bx), ey = cy ? 0.0f : 1.2e-7f * fabsf(by), ez = cz ? 0.0f : 1.2e-7f * fabsf(bz);
+        // (plus the boxes' slack in space, sc.box_slack, as a distance along the ray: a ray that runs in the plane of a box side --
+        // a clamped axis, both distances zero or astronomic -- passes as it does in exact arithmetic)
+        const float ex = 1.2e-7f * fabsf(bx) + sc.box_slack * fabsf(ix), ey = 1.2e-7f * fabsf(by) + sc.box_slack * fabsf(iy);
+        const float ez = 1.2e-7f * fabsf(bz) + sc.box_slack * fabsf(iz);
         const float bnx = bx - ex, bny = by - ey, bnz = bz - ez; // addends of entry distances
         const float bfx = bx + ex, bfy = by + ey, bfz = bz + ez; // addends of exit distances
 
@@ -624,7 +626,7 @@ struct RaySetup {
     float bnx, bny, bnz, bfx, bfy, bfz;
 };
 // Slab-test operands of a ray; see the comment in walk_kernel.
-__device__ __forceinline__ RaySetup setup_ray(V3 o, V3 d) {
+__device__ __forceinline__ RaySetup setup_ray(V3 o, V3 d, float box_slack) {
     constexpr float kInvMax = 1e25f;
     RaySetup r;
     r.ix = 1.0f / d.x, r.iy = 1.0f / d.y, r.iz = 1.0f / d.z;
@@ -634,7 +636,8 @@ __device__ __forceinline__ RaySetup setup_ray(V3 o, V3 d) {
     if (cz) r.iz = copysignf(kInvMax, d.z);
     r.offx = r.ix < 0.0f ? 16u : 0u, r.offy = r.iy < 0.0f ? 48u : 32u, r.offz = r.iz < 0.0f ? 80u : 64u;
     const float bx = -o.x * r.ix, by = -o.y * r.iy, bz = -o.z * r.iz;
-    const float ex = cx ? 0.0f : 1.2e-7f * fabsf(bx), ey = cy ? 0.0f : 1.2e-7f * fabsf(by), ez = cz ? 0.0f : 1.2e-7f * fabsf(bz);
+    const float ex = 1.2e-7f * fabsf(bx) + box_slack * fabsf(r.ix), ey = 1.2e-7f * fabsf(by) + box_slack * fabsf(r.iy);
+    const float ez = 1.2e-7f * fabsf(bz) + box_slack * fabsf(r.iz);
     r.bnx = bx - ex, r.bny = by - ey, r.bnz = bz - ez;
     r.bfx = bx + ex, r.bfy = by + ey, r.bfz = bz + ez;
     return r;
@@ -707,7 +710,7 @@ __device__ __forceinline__ void walk_steal_body(const DeviceScene &sc, const Fra
         s_tri[lane] = best_tri;
         s_cut[lane] = __float_as_int(tbest);
         int owner = lane; // the ray this lane works for = the lane that loaded it
-        RaySetup rs = setup_ray(o, d);
+        RaySetup rs = setup_ray(o, d, sc.box_slack);
         int node = valid ? 0 : kSentinel, sp = 0, base = 0, nq = 0;
         bool dirty = false; // holds an accepted face that is not published yet
         float tlimit = tbest * 1.000001f;
@@ -744,7 +747,7 @@ __device__ __forceinline__ void walk_steal_body(const DeviceScene &sc, const Fra
                 if (thief) {
                     o = mk(sox, soy, soz), d = mk(sdx, sdy, sdz);
                     owner = sowner;
-                    rs = setup_ray(o, d);
+                    rs = setup_ray(o, d, sc.box_slack);
                     node = s_stack[sbase * 64 + src];
                     sp = base = 0;
                     tbest = __int_as_float(s_cut[owner]); // nothing farther is of interest; equal distances still are (rank)

@@ -211,6 +211,103 @@ def test_projection_margins_under_attack(seed):
             assert (r["stats"].rays_shadow, r["stats"].hits) == (rt["stats"].rays_shadow, rt["stats"].hits)
 
 
+def _edge_attack_scene(size, ssaa):
+    """Faces for test_screen_space_edge_test_under_attack (arguments of Flyscene)."""
+
+    W, H = size
+    rng = np.random.default_rng(900 + W + ssaa)
+    aspect, tan_half = W / H, np.tan(np.radians(30.0))
+    eye = np.array([0.0, 0.0, 2.0])
+
+    def through(px, py, depth):  # world point on the ray of screen position (px, py) (Camera::screenToWorld, default pose)
+        nx = (2.0 * px / W - 1.0) * aspect * tan_half
+        ny = (1.0 - 2.0 * py / H) * tan_half
+        return np.stack([nx * depth, ny * depth, 2.0 - depth], -1)
+
+    tris = []
+    n = 1200
+    sub = rng.integers(0, ssaa, (n, 1)) / ssaa  # a sample of one of the passes
+    # (a) corners on sample rays, edges through the samples between them (lattice steps with a common divisor)
+    x0, y0 = rng.integers(8, W - 40, (n, 1)), rng.integers(8, H - 40, (n, 1))
+    step = rng.integers(1, 5, (n, 2)) * rng.integers(2, 5, (n, 1))
+    other = rng.integers(-6, 7, (n, 2))
+    px = np.concatenate([x0, x0 + step[:, :1], x0 + other[:, :1]], 1) + sub
+    py = np.concatenate([y0, y0 + step[:, 1:], y0 + other[:, 1:]], 1) + sub
+    depth = rng.uniform(0.6, 3.0, (n, 1)) + rng.uniform(-0.2, 0.2, (n, 3))
+    tris.append(through(px, py, depth))
+    # (b) slivers: two corners far apart, the third almost on the line between them
+    ax, ay = rng.uniform(0, W, (n, 1)), rng.uniform(0, H, (n, 1))
+    bx, by = ax + rng.uniform(-120, 120, (n, 1)), ay + rng.uniform(-120, 120, (n, 1))  # (a box beyond 16384 pixels is not this pass's)
+    t = rng.uniform(0.1, 0.9, (n, 1))
+    off = 10.0 ** rng.uniform(-4.0, -1.0, (n, 1)) * rng.choice([-1.0, 1.0], (n, 1))
+    length = np.hypot(bx - ax, by - ay) + 1e-9
+    cx, cy = ax + t * (bx - ax) - off * (by - ay) / length, ay + t * (by - ay) + off * (bx - ax) / length
+    d = rng.uniform(0.8, 2.5, (n, 1))
+    tris.append(through(np.concatenate([ax, bx, cx], 1), np.concatenate([ay, by, cy], 1), d + rng.uniform(-0.05, 0.05, (n, 3))))
+    # (c) faces far smaller than a pixel, around sample points
+    sx, sy = rng.integers(0, W, (n, 1)) + sub, rng.integers(0, H, (n, 1)) + sub
+    r = 10.0 ** rng.uniform(-3.0, -0.5, (n, 1))
+    ang = rng.uniform(0, 2 * np.pi, (n, 1)) + np.array([[0.0, 2.1, 4.2]])
+    tris.append(through(sx + r * np.cos(ang), sy + r * np.sin(ang), rng.uniform(0.8, 2.5, (n, 1)) + np.zeros((n, 3))))
+    # (d) one corner thousands of pixels off the screen, the other two near that side's border (a box of a few thousand pixels:
+    # larger ones are not this pass's, they are tested pixel by pixel in the compaction)
+    side = rng.choice([-1.0, 1.0], (n, 1))
+    gx = np.where(side < 0, rng.uniform(0, 40, (n, 2)), rng.uniform(W - 40, W, (n, 2)))
+    gy = rng.uniform(40, H - 40, (n, 1)) + rng.uniform(-20, 20, (n, 2))
+    fx = np.where(side < 0, -rng.uniform(2000.0, 15000.0, (n, 1)), W + rng.uniform(2000.0, 15000.0 - W, (n, 1)))
+    fy = gy[:, :1] + rng.uniform(-300.0, 300.0, (n, 1))
+    tris.append(through(np.concatenate([gx, fx], 1), np.concatenate([gy, fy], 1), rng.uniform(0.8, 2.5, (n, 1)) + rng.uniform(-0.1, 0.1, (n, 3))))
+    tri = np.concatenate(tris).astype(np.float32)
+    assert np.all(tri[..., 2] < eye[2] - 0.3)
+    verts = tri.reshape(-1, 3)
+    faces = np.arange(len(verts), dtype=np.int32).reshape(-1, 3)
+    mats = [dict(ka=[0.1] * 3, kd=[0.3 + 0.2 * m, 0.8 - 0.2 * m, 0.4], ks=[0.0] * 3, shininess=8.0) for m in range(3)]
+    arrays = (verts, None, faces, rng.integers(0, 3, len(faces)).astype(np.int32), mats)
+    kw = dict(arrays=arrays, lights=[(-1.0, 1.0, 1.0)], soft_points=0, normalize_model=False, output="")
+    return kw
+
+
+@pytest.mark.parametrize("size,ssaa", [((1920, 1080), 1), ((333, 777), 2), ((640, 480), 3)])
+def test_screen_space_edge_test_under_attack(size, ssaa):
+    """The face pass drops a (face, pixel) pair when the pixel's sample lies outside the PROJECTED triangle by more than a
+    margin, before the exact test sees it.  Faces chosen to sit on that decision: corners exactly on the rays of pixel
+    samples with edges through further samples (the exact test decides those pixels by its rounding), slivers a hundred
+    pixels long and a hundredth of a pixel wide (orientation of the projected triangle uncertain), faces of a ten-thousandth
+    of a pixel, corners thousands of pixels off the screen.  Against the tree walk, bit for bit, whole and as one rank's
+    share; every sub-pixel offset of the SSAA passes moves the samples."""
+    W, H = size
+    kw = _edge_attack_scene(size, ssaa)
+    auto = R.Flyscene(**kw).initialize(W, H)
+    tree = R.Flyscene(primary_rays=L.PRIMARY_RAYS_TREE, shadow_rays=L.SHADOW_RAYS_TREE, **kw).initialize(W, H)
+    for params in (dict(), dict(row_tile=16, num_parts=4, part=1)):
+        for f in (auto, tree):
+            f.set_params(max_reflections=0, ssaa_level=ssaa, **params)
+        ra, rt = auto.render(), tree.render()
+        assert rt["stats"].primary_path == 0 and ra["stats"].primary_path == 1
+        assert (rt["face_id"] >= 0).sum() > 2000
+        assert np.array_equal(ra["face_id"], rt["face_id"]), params
+        assert np.array_equal(ra["rgb"].view(np.uint32), rt["rgb"].view(np.uint32)), params
+        assert (ra["stats"].rays_shadow, ra["stats"].hits) == (rt["stats"].rays_shadow, rt["stats"].hits)
+    if W % 2 == 1 and ssaa == 2:
+        # The centre column of the last pass: its rays have a direction whose x is exactly zero and run IN the plane of a
+        # side of every box that a face with a corner at x = 0 ends at (the corners of group (a) lie on such rays).  Ray by
+        # ray against the oracle (the face ids of a frame are those of its last pass; plane distances that are not a number
+        # rejected, as the HIP path defines it: see parity_util.compare).
+        from oracle.oracle_py import OracleScene, screen_ray
+        orc = OracleScene(arrays=kw["arrays"], lights=[(-1.0, 1.0, 1.0, 1.0, 1.0, 1.0)], soft_points=0, normalize_model=False)
+        cam = orc.default_camera(W, H)
+        auto.set_params(max_reflections=0, ssaa_level=ssaa, row_tile=16, num_parts=1, part=0)
+        ra = auto.render()
+        hits = 0
+        for y in range(H):
+            d = screen_ray(cam, W // 2 + 0.5, y + 0.5)
+            assert d[0] == 0.0
+            hit, fid, _, _, _ = orc.intersects(list(cam.origin), d, reject_nan=1)
+            assert ra["face_id"][y, W // 2] == (fid if hit else -2), y
+            hits += int(hit)
+        assert hits > 20
+
+
 def test_automatic_choice_between_screen_space_and_tree():
     """Primary rays are resolved face by face in screen space unless the faces are many against the pixels (a projection per
     face then costs more than a tree walk per pixel) or too many faces reach round the eye for the per-pixel list; forced
