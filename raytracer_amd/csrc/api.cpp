@@ -602,7 +602,8 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
     float largest = 0.0f; // largest coordinate of any face
     for (const TriRecord &t : bvh.tris)
         for (int k = 0; k < 3; ++k) largest = std::max(largest, std::max(std::fabs(t.v0[k]), std::max(std::fabs(t.v1[k]), std::fabs(t.v2[k]))));
-    s->ds.box_slack = std::isfinite(largest) ? largest * 9.5367431640625e-7f : 0.0f;
+    static const float slack_rel = getenv("RTAMD_BOX_SLACK") ? (float)atof(getenv("RTAMD_BOX_SLACK")) : 9.5367431640625e-7f; // experiment hook (2^-20)
+    s->ds.box_slack = std::isfinite(largest) ? largest * slack_rel : 0.0f;
     s->ds.shade = (const float4 *)s->d_shade;
     s->ds.materials = (const float *)s->d_materials;
     s->ds.light_pos = (const float *)s->d_light_pos;

@@ -23,6 +23,8 @@ def make_pair(name=None, arrays=None, lights=None, hard_shadow=True, soft_points
               width=64, height=64, **build):
     """(Flyscene on the GPU, OracleScene on the CPU) for the same inputs."""
     kw = dict(lights=lights, hard_shadow=hard_shadow, soft_points=soft_points, soft_radius=soft_radius, spheres=spheres)
+    if "normalize_model" in build:  # (an argument of both)
+        kw["normalize_model"] = build.pop("normalize_model")
     if arrays is not None:
         fly = R.Flyscene(arrays=arrays, output="", **kw, **build)
         okw = dict(kw)

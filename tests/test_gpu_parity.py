@@ -308,6 +308,64 @@ def test_screen_space_edge_test_under_attack(size, ssaa):
         assert hits > 20
 
 
+@pytest.mark.parametrize("size", [(101, 75), (64, 49)])
+def test_rays_with_zero_direction_components(size):
+    """Axis-aligned mirrors in front of the default camera and lights on the coordinate axes: the centre row and column of
+    an odd-sized image, their reflections and the shadow rays of a light on an axis have directions with components that
+    are exactly zero, and the faces end exactly on the planes x = 0 and y = 0 those rays run in (the sides of the tree's
+    boxes, the borders of the shadow grids' cells).  Every path against the oracle, and against each other bit for bit."""
+    W, H = size
+    rng = np.random.default_rng(7 + W)
+    tris = []
+    # a mirror wall behind (z = -0.6) and a mirror floor (y = -0.5), both split along x = 0
+    for x0, x1 in ((-1.2, 0.0), (0.0, 1.2)):
+        tris += [[(x0, -0.5, -0.6), (x1, -0.5, -0.6), (x1, 0.9, -0.6)], [(x0, -0.5, -0.6), (x1, 0.9, -0.6), (x0, 0.9, -0.6)]]
+        tris += [[(x0, -0.5, -0.6), (x1, -0.5, 1.2), (x1, -0.5, -0.6)], [(x0, -0.5, -0.6), (x0, -0.5, 1.2), (x1, -0.5, 1.2)]]
+    n_mirror = len(tris)
+    # small dull faces that end exactly at x = 0 or y = 0, in front of the wall and above the floor (seen directly, in the
+    # mirrors, and as occluders of the lights on the axes)
+    for _ in range(60):
+        c = rng.uniform(-0.4, 0.4, 3) + np.array([0.0, 0.1, 0.3])
+        t = c + rng.uniform(-0.15, 0.15, (3, 3))
+        axis = int(rng.integers(0, 2))
+        side = rng.choice([-1.0, 1.0])
+        t[:, axis] = side * np.abs(t[:, axis])
+        t[int(rng.integers(0, 3)), axis] = 0.0
+        if rng.random() < 0.3:
+            t[int(rng.integers(0, 3)), axis] = 0.0  # an edge in the plane
+        tris.append(t.tolist())
+    tri = np.array(tris, np.float32)
+    verts = tri.reshape(-1, 3)
+    faces = np.arange(len(verts), dtype=np.int32).reshape(-1, 3)
+    mats = [dict(ka=[0.05] * 3, kd=[0.2, 0.2, 0.25], ks=[0.9] * 3, shininess=32.0),
+            dict(ka=[0.1] * 3, kd=[0.8, 0.5, 0.3], ks=[0.0] * 3, shininess=8.0),
+            dict(ka=[0.1] * 3, kd=[0.3, 0.6, 0.8], ks=[0.0] * 3, shininess=8.0)]
+    fmat = np.concatenate([np.zeros(n_mirror, np.int32), rng.integers(1, 3, len(faces) - n_mirror).astype(np.int32)])
+    arrays = (verts, None, faces, fmat, mats)
+    lights = [(0.0, 1.5, 0.0), (0.0, 0.0, 1.5), (1.0, 0.0, 0.0)]
+    kw = dict(arrays=arrays, lights=lights, soft_points=0, normalize_model=False, width=W, height=H)
+    fly, orc = make_pair(**kw)
+    r = compare(fly, orc, W, H, max_reflections=3)
+    assert_parity(r)
+    assert r["rays_gpu"][2] > 1000  # reflections happen
+    base = r["got"]
+    # the centre column / row really are such rays
+    cam = oracle_camera(orc, fly.getCamera())
+    from oracle.oracle_py import screen_ray
+    if W % 2 == 1:
+        assert screen_ray(cam, W // 2 + 0.5, 3.5)[0] == 0.0
+    if H % 2 == 1:
+        assert screen_ray(cam, 3.5, H // 2 + 0.5)[1] == 0.0
+    for build in (dict(primary_rays=L.PRIMARY_RAYS_TREE, shadow_rays=L.SHADOW_RAYS_TREE), dict(primary_rays=L.PRIMARY_RAYS_BINS),
+                  dict(builder=L.BUILDER_DEVICE_LBVH), dict(builder=L.BUILDER_DEVICE_LBVH, primary_rays=L.PRIMARY_RAYS_TREE, shadow_rays=L.SHADOW_RAYS_TREE)):
+        other = R.Flyscene(arrays=arrays, lights=lights, soft_points=0, normalize_model=False, output="", **build).initialize(W, H)
+        other.set_params(max_reflections=3)
+        got = other.render()
+        assert np.array_equal(got["face_id"], base["face_id"]), build
+        assert np.array_equal(got["rgb"].view(np.uint32), base["rgb"].view(np.uint32)), build
+        assert (got["stats"].rays_shadow, got["stats"].rays_bounce, got["stats"].hits) == (base["stats"].rays_shadow, base["stats"].rays_bounce, base["stats"].hits)
+
+
 def test_automatic_choice_between_screen_space_and_tree():
     """Primary rays are resolved face by face in screen space unless the faces are many against the pixels (a projection per
     face then costs more than a tree walk per pixel) or too many faces reach round the eye for the per-pixel list; forced
