@@ -604,6 +604,8 @@ int rtamd_scene_create(const rtamd_scene_desc *d, const rtamd_build_params *buil
         for (int k = 0; k < 3; ++k) largest = std::max(largest, std::max(std::fabs(t.v0[k]), std::max(std::fabs(t.v1[k]), std::fabs(t.v2[k]))));
     static const float slack_rel = getenv("RTAMD_BOX_SLACK") ? (float)atof(getenv("RTAMD_BOX_SLACK")) : 9.5367431640625e-7f; // experiment hook (2^-20)
     s->ds.box_slack = std::isfinite(largest) ? largest * slack_rel : 0.0f;
+    s->ds.box_slack_rel = slack_rel;
+    s->ds.largest_coord = std::isfinite(largest) ? largest : 0.0f;
     s->ds.shade = (const float4 *)s->d_shade;
     s->ds.materials = (const float *)s->d_materials;
     s->ds.light_pos = (const float *)s->d_light_pos;
@@ -898,6 +900,11 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
                                          0.5 * (double)p->width / std::max(1e-6, (double)std::fabs(fc.ax)));
         const double bound = px_per_n * 32.0 * unit + 6.0 * unit * (double)p->width;
         fc.raster_margin = std::max(raster_margin_floor(), (float)(4.0 * bound));
+        // the exact test's own rounding: four units in the last place of the largest coordinate it computes with (eye or face),
+        // times four, in pixels per unit of n (project_point's `spread` turns it into pixels at a corner's depth)
+        const double largest = std::max((double)s->ds.largest_coord, std::max(std::fabs((double)cam->origin[0]), std::max(std::fabs((double)cam->origin[1]), std::fabs((double)cam->origin[2]))));
+        static const double coord_rel = getenv("RTAMD_COORD_SLACK") ? atof(getenv("RTAMD_COORD_SLACK")) : 1.9073486328125e-6; // experiment hook (2^-19)
+        fc.coord_slack = (float)(coord_rel * largest * std::max((double)std::fabs(fc.px_scale), (double)std::fabs(fc.py_scale)));
     }
     fs.ws.dir_y = fs.ws.dir_x + tiles_x * 8;
     Workspace ws_frame = fs.ws; // what the kernels of this frame see

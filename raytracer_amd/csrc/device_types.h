@@ -35,10 +35,12 @@ struct DeviceScene {
     // the (up to) sixteen grandchildren of the root, where the lanes of a shared ray start (0x7fffffff: none)
     int32_t start16[16];
     int32_t num_records; // TriRecords (= planes = shading records)
-    // Slack of the tree's boxes in space: 2^-20 of the largest coordinate of any face.  The exact face test rounds, so it may accept
-    // a point a few units in the last place outside a face's own box (a ray through a corner of the face, a ray that runs IN the
-    // plane of a box side); the slab tests let a ray pass that misses a box by less than this.
-    float box_slack;
+    // Slack of the tree's boxes in space: 2^-20 of the largest coordinate of any face or of the ray's origin, whichever is larger
+    // (box_slack_rel = 2^-20).  The exact face test rounds, so it may accept a point a few units in the last place of those
+    // coordinates outside a face's own box (a ray through a corner of the face, a ray that runs IN the plane of a box side); the
+    // slab tests let a ray pass that misses a box by less than this.
+    float box_slack, box_slack_rel;
+    float largest_coord; // largest coordinate of any face
 };
 
 // Per-launch constants (camera + the reference's macros).
@@ -65,6 +67,10 @@ struct FrameConst {
     float px_off, px_scale, py_off, py_scale;   // pixel = (px_off + n.x * px_scale, py_off - n.y * py_scale) for a direction n of the camera
     int32_t bins_x, bins_y;
     float raster_margin; // widening of projected boxes and triangles in pixels (error bound: RT_BIN_MARGIN in kernels.hip)
+    // ... plus coord_slack times a corner's spread (project_point): the exact test computes with the coordinates themselves, so its
+    // decisions are only good to a few units in the last place of the LARGEST coordinate involved (eye or face), which is more
+    // pixels the nearer the face is to the eye: coord_slack = 2^-19 * that coordinate * the projection's pixels per unit of n
+    float coord_slack;
 };
 
 constexpr int kBinPixels = 4;   // screen bin edge; an 8x8 slot tile holds four bins

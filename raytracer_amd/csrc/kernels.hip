@@ -410,8 +410,9 @@ __global__ __launch_bounds__(64, RT_WAVES_PER_SIMD) void walk_kernel(DeviceScene
         const float bx = -o.x * ix, by = -o.y * iy, bz = -o.z * iz;
         // (plus the boxes' slack in space, sc.box_slack, as a distance along the ray: a ray that runs in the plane of a box side --
         // a clamped axis, both distances zero or astronomic -- passes as it does in exact arithmetic)
-        const float ex = 1.2e-7f * fabsf(bx) + sc.box_slack * fabsf(ix), ey = 1.2e-7f * fabsf(by) + sc.box_slack * fabsf(iy);
-        const float ez = 1.2e-7f * fabsf(bz) + sc.box_slack * fabsf(iz);
+        const float slack = fmaxf(sc.box_slack, sc.box_slack_rel * fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)));
+        const float ex = 1.2e-7f * fabsf(bx) + slack * fabsf(ix), ey = 1.2e-7f * fabsf(by) + slack * fabsf(iy);
+        const float ez = 1.2e-7f * fabsf(bz) + slack * fabsf(iz);
         const float bnx = bx - ex, bny = by - ey, bnz = bz - ez; // addends of entry distances
         const float bfx = bx + ex, bfy = by + ey, bfz = bz + ez; // addends of exit distances
 
@@ -626,7 +627,8 @@ struct RaySetup {
     float bnx, bny, bnz, bfx, bfy, bfz;
 };
 // Slab-test operands of a ray; see the comment in walk_kernel.
-__device__ __forceinline__ RaySetup setup_ray(V3 o, V3 d, float box_slack) {
+__device__ __forceinline__ RaySetup setup_ray(V3 o, V3 d, float scene_slack, float slack_rel) {
+    const float box_slack = fmaxf(scene_slack, slack_rel * fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)));
     constexpr float kInvMax = 1e25f;
     RaySetup r;
     r.ix = 1.0f / d.x, r.iy = 1.0f / d.y, r.iz = 1.0f / d.z;
@@ -710,7 +712,7 @@ __device__ __forceinline__ void walk_steal_body(const DeviceScene &sc, const Fra
         s_tri[lane] = best_tri;
         s_cut[lane] = __float_as_int(tbest);
         int owner = lane; // the ray this lane works for = the lane that loaded it
-        RaySetup rs = setup_ray(o, d, sc.box_slack);
+        RaySetup rs = setup_ray(o, d, sc.box_slack, sc.box_slack_rel);
         int node = valid ? 0 : kSentinel, sp = 0, base = 0, nq = 0;
         bool dirty = false; // holds an accepted face that is not published yet
         float tlimit = tbest * 1.000001f;
@@ -747,7 +749,7 @@ __device__ __forceinline__ void walk_steal_body(const DeviceScene &sc, const Fra
                 if (thief) {
                     o = mk(sox, soy, soz), d = mk(sdx, sdy, sdz);
                     owner = sowner;
-                    rs = setup_ray(o, d, sc.box_slack);
+                    rs = setup_ray(o, d, sc.box_slack, sc.box_slack_rel);
                     node = s_stack[sbase * 64 + src];
                     sp = base = 0;
                     tbest = __int_as_float(s_cut[owner]); // nothing farther is of interest; equal distances still are (rank)
@@ -937,6 +939,14 @@ struct PixelBox {
 // (R / s <= 20 at 1080p: 0.009 pixel).  The exact test's own rounding moves a face's boundary by a few u of the face's
 // size in pixels (0.001 pixel for a face 10^4 pixels wide).  The floor of a sixteenth of a pixel is six times the 8K bound;
 // beyond that the host scales the margin with the image.
+// All of this takes coordinates of the size of the depths.  The exact test computes with the coordinates themselves (the hit
+// point is eye + t * direction, rounded to the last place of the EYE's coordinates; the plane's D and eye . n cancel at that
+// size), so where the eye and the faces lie far from the origin and near each other its decisions are only good to about four
+// units in the last place of the largest coordinate: 2.4e-4 for an eye a thousand units out, a quarter of a pixel for a face two
+// units away at 4K.  A face's margin is therefore raster_margin + coord_slack * spread, coord_slack = 2^-19 (sixteen such
+// units) * largest coordinate * pixels per unit of n, spread = (1 + |n.x| + |n.y|) / s of the face's nearest corner: a thousandth
+// of a pixel for the reference's own scenes (coordinates within the unit cube, depths of one or two), tens of pixels ten
+// thousand units out, where the faces' boxes outgrow the pass and it gives way to the tree.
 // It matters that the margin is not larger than needed for faces smaller than a pixel (a distant mesh): their box holds a
 // pixel centre with probability (size + 2 margin)^2, and a quarter of a pixel made the work 3-4 times what it had to be.
 #ifndef RT_BIN_MARGIN
@@ -946,7 +956,10 @@ constexpr float kBinMarginFloor = RT_BIN_MARGIN;
 
 // pixel position of a world point: inverse of camera_direction.  false: the point is not in front of the eye.
 // `behind`: the point lies behind the eye plane by far more than any rounding here or in the exact test.
-__device__ __forceinline__ bool project_point(const FrameConst &fc, V3 p, float &px, float &py, bool &behind) {
+// `spread`: pixels that a displacement of the point by one unit of length moves its image by, at most (sideways 1 / s of the
+// projection's scale, in depth |n| / s of it), in units of the projection's scale.
+__device__ __forceinline__ bool project_point(const FrameConst &fc, V3 p, float &px, float &py, bool &behind, float &spread) {
+    spread = 0.0f;
     const V3 r = p - mk(fc.origin[0], fc.origin[1], fc.origin[2]);
     const float *m = fc.lin_inv;
     const float qx = m[0] * r.x + (m[1] * r.y + m[2] * r.z);
@@ -961,6 +974,7 @@ __device__ __forceinline__ bool project_point(const FrameConst &fc, V3 p, float 
     const float nx = qx * rs - fc.cam_e[0], ny = qy * rs - fc.cam_e[1];
     px = fc.px_off + nx * fc.px_scale;
     py = fc.py_off - ny * fc.py_scale;
+    spread = fabsf(rs) * (1.0f + fabsf(qx * rs) + fabsf(qy * rs));
     return px == px && py == py;
 }
 
@@ -971,17 +985,20 @@ struct ProjectedFace {
     bool unbounded; // a corner beside or behind the eye: the box is the whole image
     float x0, y0, x1, y1, x2, y2;
     int px0, py0, px1, py1;
+    float margin; // widening of the face's box and projected triangle, in pixels: the pass's margin plus the term of the coordinates' size
 };
 __device__ __forceinline__ ProjectedFace project_face(const DeviceScene &sc, const FrameConst &fc, int tri) {
     ProjectedFace f;
     f.empty = false, f.unbounded = false;
     f.x0 = f.y0 = f.x1 = f.y1 = f.x2 = f.y2 = 0.0f;
     f.px0 = f.py0 = 0, f.px1 = f.py1 = -1;
+    f.margin = fc.raster_margin;
     const float4 p0 = sc.tris[tri * 4 + 1], p1 = sc.tris[tri * 4 + 2], p2 = sc.tris[tri * 4 + 3];
     bool back0, back1, back2;
-    const bool ok0 = project_point(fc, mk(p0.x, p0.y, p0.z), f.x0, f.y0, back0);
-    const bool ok1 = project_point(fc, mk(p1.x, p1.y, p1.z), f.x1, f.y1, back1);
-    const bool ok2 = project_point(fc, mk(p2.x, p2.y, p2.z), f.x2, f.y2, back2);
+    float spread0, spread1, spread2;
+    const bool ok0 = project_point(fc, mk(p0.x, p0.y, p0.z), f.x0, f.y0, back0, spread0);
+    const bool ok1 = project_point(fc, mk(p1.x, p1.y, p1.z), f.x1, f.y1, back1, spread1);
+    const bool ok2 = project_point(fc, mk(p2.x, p2.y, p2.z), f.x2, f.y2, back2, spread2);
     // Every point a primary ray reaches at a positive distance lies in front of the eye plane (s > 0 above, and s is
     // linear in the point); a face with all three corners clearly behind that plane lies behind it entirely and can
     // meet no such ray.  Without this, a view from inside or past the mesh sent those faces to the list every pixel scans.
@@ -993,7 +1010,8 @@ __device__ __forceinline__ ProjectedFace project_face(const DeviceScene &sc, con
     if (ok0 && ok1 && ok2) {
         // pixel (x, y) samples at (x + sub_x, y + sub_y): shift the box instead of the samples; the margin covers
         // the rounding of the projection (about 1e-3 pixel at 8K) and of the exact test many times over
-        const float margin = fc.raster_margin;
+        // (fc.coord_slack: what the exact test's rounding of coordinates of the scene's size is in pixels at unit spread)
+        const float margin = f.margin = fc.raster_margin + fc.coord_slack * fmaxf(fmaxf(spread0, spread1), spread2);
         xlo = fminf(fminf(f.x0, f.x1), f.x2) - margin - fc.sub_x, xhi = fmaxf(fmaxf(f.x0, f.x1), f.x2) + margin - fc.sub_x;
         ylo = fminf(fminf(f.y0, f.y1), f.y2) - margin - fc.sub_y, yhi = fmaxf(fmaxf(f.y0, f.y1), f.y2) + margin - fc.sub_y;
     } else {
@@ -1013,8 +1031,8 @@ __device__ __forceinline__ ProjectedFace project_face(const DeviceScene &sc, con
 __device__ __forceinline__ PixelBox face_bins(const DeviceScene &sc, const FrameConst &fc, int tri) {
     PixelBox b;
     b.empty = false, b.big = false, b.cull = false;
-    b.margin = fc.raster_margin;
     const ProjectedFace pf = project_face(sc, fc, tri);
+    b.margin = pf.margin;
     if (pf.empty) {
         b.empty = true;
         b.x0 = b.y0 = 0, b.x1 = b.y1 = -1;
@@ -1276,7 +1294,9 @@ __device__ __forceinline__ bool cluster_outside_part(const DeviceScene &sc, cons
     }
     const float lim = 1e6f;
     if (!(fabsf(xlo) < lim && fabsf(xhi) < lim && fabsf(ylo) < lim && fabsf(yhi) < lim)) return false; // (also: not a number)
-    const float slack = fc.raster_margin + 2.0f;
+    float spread = fabsf(rs) * (1.0f + fabsf(qx * rs) + fabsf(qy * rs)); // as in project_point
+    for (int off = 1; off < 8; off <<= 1) spread = fmaxf(spread, __shfl_xor(spread, off, 64));
+    const float slack = fc.raster_margin + fc.coord_slack * spread + 2.0f;
     const float fx0 = fmaxf(ceilf(xlo - slack - fc.sub_x), 0.0f), fy0 = fmaxf(ceilf(ylo - slack - fc.sub_y), 0.0f);
     const float fx1 = fminf(floorf(xhi + slack - fc.sub_x), (float)(fc.width - 1)), fy1 = fminf(floorf(yhi + slack - fc.sub_y), (float)(fc.height - 1));
     if (fx0 > fx1 || fy0 > fy1) return true; // off the screen
@@ -1415,7 +1435,7 @@ __device__ __forceinline__ EdgeFilter edge_filter(const FrameConst &fc, const Pr
     // corners relative to the sample of the box's first pixel
     const float ox = (float)f.px0 + fc.sub_x, oy = (float)f.py0 + fc.sub_y;
     const float px[3] = {f.x0 - ox, f.x1 - ox, f.x2 - ox}, py[3] = {f.y0 - oy, f.y1 - oy, f.y2 - oy};
-    const float margin = 1.25f * fc.raster_margin;
+    const float margin = 1.25f * f.margin;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int n = k == 2 ? 0 : k + 1;
@@ -1493,7 +1513,7 @@ __global__ __launch_bounds__(64 * kFilterWaves) void face_raster_kernel(DeviceSc
     unsigned w_box = 0, w_plane = 0, w_edge = 0;
     ProjectedFace f;
     f.empty = true, f.unbounded = false, f.px0 = f.py0 = 0, f.px1 = f.py1 = -1;
-    f.x0 = f.y0 = f.x1 = f.y1 = f.x2 = f.y2 = 0.0f;
+    f.x0 = f.y0 = f.x1 = f.y1 = f.x2 = f.y2 = 0.0f, f.margin = fc.raster_margin;
     // a rank that renders some rows only: groups of faces that lie in other ranks' rows are dropped unseen
     // (a wave's faces lie in one group of 64 records: 1 << fshift divides 64)
     bool skip = false;

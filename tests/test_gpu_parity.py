@@ -366,6 +366,61 @@ def test_rays_with_zero_direction_components(size):
         assert (got["stats"].rays_shadow, got["stats"].rays_bounce, got["stats"].hits) == (base["stats"].rays_shadow, base["stats"].rays_bounce, base["stats"].hits)
 
 
+def _far_scene(translate, seed, n=3000, size=0.08, ks=0.0):
+    """A soup of small faces two units in front of a camera that has been moved by `translate` (Flycamera steps), with its
+    light: coordinates as large as the camera's, depths of about two."""
+    rng = np.random.default_rng(seed)
+    one = (np.zeros((3, 3), np.float32), None, np.array([[0, 1, 2]], np.int32), np.zeros(1, np.int32),
+           [dict(ka=[0.1] * 3, kd=[0.5] * 3, ks=[0.0] * 3, shininess=8.0)])
+    probe = R.Flyscene(arrays=one, lights=[(0, 0, 0)], soft_points=0, normalize_model=False, output="").initialize(64, 64, upload=False)
+    probe.camera_translate(*translate)
+    eye = np.array(list(probe.getCamera().origin), np.float64)
+    centre = eye + np.array([0.0, 0.0, -2.0])
+    c = centre + rng.uniform(-0.8, 0.8, (n, 1, 3)) * np.array([1.6, 0.9, 0.5])
+    tri = (c + rng.uniform(-size, size, (n, 3, 3))).astype(np.float32)
+    verts = tri.reshape(-1, 3)
+    faces = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    mats = [dict(ka=[0.1] * 3, kd=[0.3 + 0.2 * m, 0.8 - 0.2 * m, 0.4], ks=[ks] * 3, shininess=8.0) for m in range(3)]
+    arrays = (verts, None, faces, rng.integers(0, 3, n).astype(np.int32), mats)
+    light = tuple((centre + np.array([-1.0, 1.0, 1.0])).tolist())
+    return arrays, [light], eye
+
+
+@pytest.mark.parametrize("translate", [(1200.0, -900.0, 1300.0), (12000.0, -9000.0, 13000.0), (150000.0, 90000.0, -130000.0)])
+def test_scene_far_from_the_origin_seen_from_nearby(translate):
+    """The exact test computes with the coordinates themselves: with an eye and faces a thousand units from the origin and two
+    units apart, its decisions are good to a few units in the last place of 1000, which is a tenth of a pixel and more at 4K.
+    The margins of the screen-space structures and the slack of the tree's boxes grow with the largest coordinate
+    (FrameConst::coord_slack, DeviceScene::box_slack); with the fixed sixteenth of a pixel the face pass lost 33 pixels of
+    this frame.  Face pass and screen bins against the tree walk at 4K, bit for bit, and everything against the oracle on a
+    small image with reflections."""
+    arrays, lights, eye = _far_scene(translate, 5)
+    assert np.abs(eye).max() > 50.0
+    kw = dict(arrays=arrays, lights=lights, soft_points=0, normalize_model=False, output="")
+    W, H = 3840, 2160
+    out = []
+    for build in (dict(primary_rays=L.PRIMARY_RAYS_TREE, shadow_rays=L.SHADOW_RAYS_TREE), dict(), dict(primary_rays=L.PRIMARY_RAYS_BINS)):
+        f = R.Flyscene(**kw, **build).initialize(W, H)
+        f.camera_translate(*translate)
+        f.set_params(max_reflections=0)
+        out.append(f.render())
+        f.close()
+    assert out[0]["stats"].primary_path == 0 and out[2]["stats"].primary_path == 1
+    # (ten thousand units out the margins are tens of pixels, the faces' boxes pass 16384 pixels and the face pass gives way)
+    assert out[1]["stats"].primary_path == (1 if np.abs(eye).max() < 2000.0 else 0)
+    assert (out[0]["face_id"] >= 0).sum() > 1000000
+    for r in out[1:]:
+        assert np.array_equal(r["face_id"], out[0]["face_id"])
+        assert np.array_equal(r["rgb"].view(np.uint32), out[0]["rgb"].view(np.uint32))
+        assert (r["stats"].rays_shadow, r["stats"].hits) == (out[0]["stats"].rays_shadow, out[0]["stats"].hits)
+    arrays, lights, _ = _far_scene(translate, 6, n=400, size=0.25, ks=0.6)
+    fly, orc = make_pair(arrays=arrays, lights=lights, soft_points=2, normalize_model=False, width=96, height=54)
+    fly.camera_translate(*translate)
+    r = compare(fly, orc, 96, 54, max_reflections=2)
+    assert_parity(r)
+    assert r["rays_gpu"][2] > 500
+
+
 def test_automatic_choice_between_screen_space_and_tree():
     """Primary rays are resolved face by face in screen space unless the faces are many against the pixels (a projection per
     face then costs more than a tree walk per pixel) or too many faces reach round the eye for the per-pixel list; forced
