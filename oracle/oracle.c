@@ -834,22 +834,35 @@ typedef struct {
     int32_t *face_id;
     unsigned tid, nthreads;
     int32_t *nan_mask;
-    int nan_flag; /* set when a NaN plane distance is met; reset per pixel */
+    int nan_flag; /* set when a NaN plane distance or a 0 / 0 in a box test is met; reset per pixel */
 } tctx;
 
-/* boundingBox::boxIntersection, boundingBox.h:257-286 */
-static int box_intersection(const orc_node *b, v3 o, v3 d) {
+/* boundingBox::boxIntersection, boundingBox.h:257-286.
+ * A ray that runs IN the plane of a box side (direction component exactly zero, origin coordinate equal to the side's)
+ * makes the reference divide 0 by 0; with its min/max and comparisons a box that ENDS at that plane is then turned away
+ * and one that STARTS there is taken, so the outcome depends on the boxes the hierarchy happens to have.  Such a ray is
+ * flagged like a NaN plane distance (nan_flag), and with reject_nan set the slab counts as passed, which is what exact
+ * arithmetic gives (the ray touches the box) and what the HIP path, which has other boxes, defines. */
+static int box_intersection(tctx *c, const orc_node *b, v3 o, v3 d) {
     float tx_min = (b->vmin.x - o.x) / d.x, tx_max = (b->vmax.x - o.x) / d.x;
+    float ty_min = (b->vmin.y - o.y) / d.y, ty_max = (b->vmax.y - o.y) / d.y;
+    float tz_min = (b->vmin.z - o.z) / d.z, tz_max = (b->vmax.z - o.z) / d.z;
+    if (tx_min != tx_min || tx_max != tx_max || ty_min != ty_min || ty_max != ty_max || tz_min != tz_min || tz_max != tz_max) {
+        c->nan_flag = 1;
+        if (c->prm->reject_nan) {
+            if (tx_min != tx_min || tx_max != tx_max) tx_min = -INFINITY, tx_max = INFINITY;
+            if (ty_min != ty_min || ty_max != ty_max) ty_min = -INFINITY, ty_max = INFINITY;
+            if (tz_min != tz_min || tz_max != tz_max) tz_min = -INFINITY, tz_max = INFINITY;
+        }
+    }
     if (tx_min > tx_max) {
         float t = tx_min;
         tx_min = tx_max, tx_max = t;
     }
-    float ty_min = (b->vmin.y - o.y) / d.y, ty_max = (b->vmax.y - o.y) / d.y;
     if (ty_min > ty_max) {
         float t = ty_min;
         ty_min = ty_max, ty_max = t;
     }
-    float tz_min = (b->vmin.z - o.z) / d.z, tz_max = (b->vmax.z - o.z) / d.z;
     if (tz_min > tz_max) {
         float t = tz_min;
         tz_min = tz_max, tz_max = t;
@@ -865,7 +878,7 @@ static int box_intersection(const orc_node *b, v3 o, v3 d) {
 /* boundingBox::intersectingBoxes, boundingBox.h:295-307 */
 static void intersecting_boxes(tctx *c, const orc_node *b, v3 o, v3 d) {
     ++c->cnt.box_tests;
-    if (!box_intersection(b, o, d)) return;
+    if (!box_intersection(c, b, o, d) && !c->prm->all_faces) return;
     if (!b->child[0]) {
         if (c->leaves.n == c->leaves.cap) {
             c->leaves.cap = c->leaves.cap ? c->leaves.cap * 2 : 256;

@@ -57,7 +57,15 @@ typedef struct {
     int32_t num_threads;          /* 0 = hardware_concurrency, flyscene.cpp:415 */
     int32_t row_offset, row_step; /* render only rows y = row_offset + k*row_step (bounded timing samples); 0,1 = all */
     int32_t reject_nan;           /* 0 = as the reference: a NaN plane distance passes both range tests and is accepted
-                                     (flyscene.cpp:760); 1 = such faces are skipped */
+                                     (flyscene.cpp:760), and a 0 / 0 in a box test (a ray IN the plane of a box side,
+                                     boundingBox.h:258-271) turns away or takes the box depending on the side; 1 = such
+                                     faces are skipped and such a slab counts as passed (no decision is left to a 0 / 0) */
+    int32_t all_faces;            /* 1 = no box turns a ray away: every leaf is visited, in the reference's order, and the faces
+                                     are accepted by the face test alone (flyscene.cpp:752-789).  The reference's own box test
+                                     (boundingBox.h:257-286) rounds, and a ray through a corner of a leaf's box may be turned
+                                     away from a face that the face test would accept; which rays depends on the boxes the
+                                     hierarchy happens to have.  The HIP path has other boxes and defines the outcome by the
+                                     face test alone: it is compared with this mode where the two differ. */
 } orc_params;
 
 typedef struct {

@@ -40,6 +40,7 @@ class Params(C.Structure):
         ("row_offset", C.c_int32),
         ("row_step", C.c_int32),
         ("reject_nan", C.c_int32),
+        ("all_faces", C.c_int32),
     ]
 
 

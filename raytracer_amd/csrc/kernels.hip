@@ -31,8 +31,11 @@
 // and the grid projection are the only places with explicit fused multiply-adds, reciprocals or free
 // evaluation order; they are conservative (intervals and boxes are widened far beyond their rounding), and
 // a widened candidate test can only add faces to be tested exactly.
-// Deliberate deviation: a NaN plane distance (ray inside a face plane, 0/0) is rejected, whereas
-// the reference accepts it and then returns a visiting-order-dependent face.
+// Deliberate deviations, all on rays whose outcome in the reference hangs on a 0 / 0 or on the last bit of ITS box test:
+// a NaN plane distance (ray inside a face plane, 0/0) is rejected, whereas the reference accepts it and then returns a
+// visiting-order-dependent face; and no box ever turns a ray away from a face that the face test accepts, whereas the
+// reference's rounded box test (src/boundingBox.h:257-286) may do so for a ray through a corner of a leaf's box, and its 0 / 0
+// for a ray that runs in the plane of a box side turns away a box that ends there and takes one that starts there.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -52,8 +52,13 @@ def oracle_camera(orc, cam):
     return c
 
 
-def compare(fly, orc, width, height, **params):
+def compare(fly, orc, width, height, all_faces=False, **params):
     """Render with both and return a dict of agreement figures.
+
+    all_faces: a third oracle run in which no box turns a ray away (every face is tried, in the reference's order; NaN
+    decisions rejected): the HIP path's definition of a frame, to be matched on EVERY pixel.  The reference's own box test
+    rounds and may turn a ray away from a face its face test accepts (a ray through a corner of a leaf's box); scenes built
+    to put rays there are compared with this run, and with the faithful run wherever the two oracle runs agree.
 
     The oracle is run twice: as the reference behaves (NaN plane distances accepted) and with NaN
     distances rejected, which is what the HIP path defines.  Agreement is demanded against the
@@ -72,7 +77,23 @@ def compare(fly, orc, width, height, **params):
     err = np.abs(got["rgb"] - ref["rgb"]).max(axis=-1)
     err2 = np.abs(got["rgb"] - ref2["rgb"]).max(axis=-1)
     st, cnt = got["stats"], ref2["counters"]
+    extra = {}
+    if all_faces:
+        ref3 = orc.render(width, height, camera=cam, reject_nan=1, all_faces=1, **okw)
+        same3 = got["face_id"] == ref3["face_id"]
+        err3 = np.abs(got["rgb"] - ref3["rgb"]).max(axis=-1)
+        boxes_agree = (ref3["face_id"] == ref2["face_id"]) & (np.abs(ref3["rgb"] - ref2["rgb"]).max(axis=-1) == 0)
+        extra = {
+            "face_mismatch_pixels_all_faces": int((~same3).sum()),
+            "bad_pixels_all_faces": int((err3 > PIXEL_TOL).sum()),
+            "rays_oracle_all_faces": (ref3["counters"].rays_primary, ref3["counters"].rays_shadow, ref3["counters"].rays_bounce),
+            "box_dependent_pixels": int((~boxes_agree).sum()),  # pixels the reference's boxes decide
+            "face_mismatch_pixels_where_boxes_agree": int((~same2 & boxes_agree).sum()),
+            "bad_pixels_where_boxes_agree": int(((err2 > PIXEL_TOL) & boxes_agree).sum()),
+            "ref_all_faces": ref3,
+        }
     return {
+        **extra,
         "pixels": width * height,
         "nan_pixels": int((~clean).sum()),
         "face_match": float(same[clean].mean()) if clean.any() else 1.0,

@@ -421,6 +421,56 @@ def test_scene_far_from_the_origin_seen_from_nearby(translate):
     assert r["rays_gpu"][2] > 500
 
 
+@pytest.mark.parametrize("size,step,ssaa", [((128, 96), 4, 1), ((97, 131), 3, 1), ((64, 64), 2, 2)])
+def test_watertight_mesh_with_corners_and_edges_on_the_sample_rays(size, step, ssaa):
+    """A height field whose corners lie on the rays of every step-th pixel sample: those rays pass through a corner shared by
+    six faces, the rays of the samples between them run along shared edges and diagonals.  Which face such a ray hits, or
+    whether it slips between two, is decided by the last bit of the reference's arithmetic and by its visiting order;
+    every path must decide like the oracle, for the primary rays, the shadow rays that start on those corners and edges, and
+    the reflections."""
+    W, H = size
+    rng = np.random.default_rng(31 + W + step)
+    aspect, tan_half = W / H, np.tan(np.radians(30.0))
+    nx_, ny_ = W // step + 3, H // step + 3
+    ix, iy = np.meshgrid(np.arange(nx_) - 1, np.arange(ny_) - 1, indexing="xy")
+    px, py = ix * step + (ssaa - 1) / ssaa, iy * step + (ssaa - 1) / ssaa  # samples of the LAST pass (whose face ids a frame reports)
+    depth = 2.4 + 0.35 * np.sin(ix * 0.37) * np.cos(iy * 0.29) + rng.uniform(-0.02, 0.02, ix.shape)
+    nx = (2.0 * px / W - 1.0) * aspect * tan_half
+    ny = (1.0 - 2.0 * py / H) * tan_half
+    verts = np.stack([nx * depth, ny * depth, 2.0 - depth], -1).reshape(-1, 3).astype(np.float32)
+    idx = (iy + 1) * nx_ + (ix + 1)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, 1:].ravel(), idx[1:, :-1].ravel()
+    flip = rng.random(a.shape) < 0.5  # the quads' diagonals alternate at random
+    t0 = np.where(flip[:, None], np.stack([a, b, d], 1), np.stack([a, b, c], 1))
+    t1 = np.where(flip[:, None], np.stack([b, c, d], 1), np.stack([a, c, d], 1))
+    faces = np.concatenate([t0, t1]).astype(np.int32)
+    mats = [dict(ka=[0.1] * 3, kd=[0.7, 0.4, 0.3], ks=[0.0] * 3, shininess=8.0), dict(ka=[0.05] * 3, kd=[0.3, 0.5, 0.7], ks=[0.5] * 3, shininess=32.0)]
+    arrays = (verts, None, faces, rng.integers(0, 2, len(faces)).astype(np.int32), mats)
+    lights = [(-1.0, 1.0, 1.0), (0.6, 0.3, 1.8)]
+    kw = dict(arrays=arrays, lights=lights, soft_points=2, normalize_model=False, width=W, height=H)
+    fly, orc = make_pair(**kw)
+    r = compare(fly, orc, W, H, all_faces=True, max_reflections=2, ssaa_level=ssaa)
+    # The HIP path accepts a face by the face test alone: it must equal the oracle run in which no box turns a ray away, on
+    # every pixel; and the faithful run wherever the reference's own boxes do not decide (a ray through a corner of a leaf's
+    # box may be turned away by the reference's rounded box test from a face its face test accepts: a handful of these rays).
+    assert r["face_mismatch_pixels_all_faces"] == 0 and r["bad_pixels_all_faces"] == 0
+    assert r["rays_gpu"] == r["rays_oracle_all_faces"]
+    assert r["face_mismatch_pixels_where_boxes_agree"] == 0 and r["bad_pixels_where_boxes_agree"] == 0
+    assert r["box_dependent_pixels"] <= 2e-3 * W * H
+    # (the mesh covers the image, but a tenth of these rays slips between two faces: the reference's edge functions turn a point
+    # on a shared edge away from both sides when the last bit falls that way, and so does every path here)
+    assert 0.8 < (r["got"]["face_id"] >= 0).mean() < 1.0 and r["rays_gpu"][2] > 100
+    base = r["got"]
+    for build in (dict(primary_rays=L.PRIMARY_RAYS_TREE, shadow_rays=L.SHADOW_RAYS_TREE), dict(primary_rays=L.PRIMARY_RAYS_BINS),
+                  dict(builder=L.BUILDER_DEVICE_LBVH), dict(builder=L.BUILDER_DEVICE_LBVH, primary_rays=L.PRIMARY_RAYS_TREE, shadow_rays=L.SHADOW_RAYS_TREE)):
+        other = R.Flyscene(arrays=arrays, lights=lights, soft_points=2, normalize_model=False, output="", **build).initialize(W, H)
+        other.set_params(max_reflections=2, ssaa_level=ssaa)
+        got = other.render()
+        assert np.array_equal(got["face_id"], base["face_id"]), build
+        assert np.array_equal(got["rgb"].view(np.uint32), base["rgb"].view(np.uint32)), build
+        assert (got["stats"].rays_shadow, got["stats"].rays_bounce, got["stats"].hits) == (base["stats"].rays_shadow, base["stats"].rays_bounce, base["stats"].hits)
+
+
 def test_automatic_choice_between_screen_space_and_tree():
     """Primary rays are resolved face by face in screen space unless the faces are many against the pixels (a projection per
     face then costs more than a tree walk per pixel) or too many faces reach round the eye for the per-pixel list; forced
