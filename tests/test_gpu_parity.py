@@ -739,6 +739,18 @@ def test_non_square_and_ragged_sizes():
         assert_parity(compare(fly, orc, w, h))
 
 
+@pytest.mark.parametrize("size", [(65535, 9), (65536, 9), (9, 65537), (70001, 5)])
+def test_images_at_and_beyond_the_screen_space_limit(size):
+    """The face pass and the screen bins pack pixel columns and rows into 16 bits: an image 65 536 wide or high goes through
+    the tree walk, one of 65 535 still through the face pass.  Both against the oracle."""
+    w, h = size
+    fly, orc = make_pair("reflect_test", width=w, height=h)
+    r = compare(fly, orc, w, h, max_reflections=2)
+    assert_parity(r)
+    assert r["got"]["stats"].primary_path == (1 if max(w, h) < 65536 else 0)
+    assert (r["got"]["face_id"] >= 0).sum() >= 2  # (a strip that wide sees the scene in its middle pixels only)
+
+
 def test_hard_shadows_two_lights_no_bounce():
     lights = [(-1.0, 1.0, 1.0), (1.0, 1.0, 1.0)]
     fly, orc = make_pair("bunny", lights=lights, soft_points=0, width=128, height=128)
