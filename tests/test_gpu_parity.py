@@ -841,12 +841,14 @@ def test_device_entry_point_matches_host_entry_point_and_is_repeatable():
     assert st.rays_shadow == st.hits * 13
 
 
-@pytest.mark.parametrize("parts,tile", [(2, 16), (3, 8), (8, 16), (5, 7)])
-def test_row_tile_parts_assemble_to_the_full_frame(parts, tile):
+@pytest.mark.parametrize("parts,tile,kw", [(2, 16, {}), (3, 8, {}), (8, 16, {}), (5, 7, {}), (3, 16, dict(ssaa_level=2, max_reflections=2)),
+                                           (4, 5, dict(ssaa_level=3, max_reflections=1))])
+def test_row_tile_parts_assemble_to_the_full_frame(parts, tile, kw):
     """Every part rendered on its own and interleaved back must equal the single-part frame bit for bit."""
     import torch
 
     fly, _ = make_pair("toy", width=96, height=100)
+    fly.set_params(**kw)
     full = fly.render()
     base = fly.params_copy(row_tile=tile)
     packed, packed_id = [], []
