@@ -767,6 +767,33 @@ def test_many_lights_deep_reflections():
     assert_parity(compare(fly, orc, 64, 64, max_reflections=3))
 
 
+def test_more_lights_than_fit_the_shading_kernels_lds_and_the_shadow_ray_limit():
+    """The shading kernel keeps up to 64 light positions in LDS and reads more from memory; a hit casts at most 512 shadow
+    rays (lights x samples).  70 lights with hard shadows, 39 lights with 13 samples each (507 rays per hit) and lights added
+    after the samples were made, against the oracle; 40 x 13 = 520 is refused at scene creation."""
+    rng = np.random.default_rng(3)
+    many = [tuple(p) for p in (rng.uniform(-1.0, 1.0, (70, 3)) * [2.0, 0.5, 2.0] + [0.0, 1.5, 0.5]).tolist()]
+    fly, orc = make_pair("reflect_test", lights=many, soft_points=0, width=48, height=40)
+    r = compare(fly, orc, 48, 40, max_reflections=2)
+    assert_parity(r)
+    assert r["rays_gpu"][1] == 70 * r["got"]["stats"].hits
+    fly, orc = make_pair("toy", lights=many[:39], soft_points=12, width=40, height=32)
+    r = compare(fly, orc, 40, 32, max_reflections=1)
+    assert_parity(r)
+    assert r["rays_gpu"][1] == 507 * r["got"]["stats"].hits
+    # lights added after initialize are shaded but cast no shadow rays: 60 sampled + 10 unsampled = 70 in the Phong loop
+    fly, orc = make_pair("reflect_test", lights=many[:60], soft_points=1, width=48, height=40)
+    for k in range(10):  # (Flyscene::addLight puts the light where the camera is, src/flyscene.hpp:76)
+        fly.camera_translate(0.3 * (k % 3 - 1), 0.2, -0.5 * (k % 2))
+        fly.addLight()
+        orc.add_light(list(fly.getCamera().origin))
+    r = compare(fly, orc, 48, 40, max_reflections=1)
+    assert_parity(r)
+    assert r["rays_gpu"][1] == 120 * r["got"]["stats"].hits
+    with pytest.raises(RuntimeError, match="shadow rays per hit"):
+        make_pair("toy", lights=many[:40], soft_points=12, width=40, height=32)
+
+
 def test_bounce_depth_sweep():
     fly, orc = make_pair("reflect_test", width=64, height=64)
     rays = []
