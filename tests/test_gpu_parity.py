@@ -794,6 +794,20 @@ def test_more_lights_than_fit_the_shading_kernels_lds_and_the_shadow_ray_limit()
         make_pair("toy", lights=many[:40], soft_points=12, width=40, height=32)
 
 
+def test_as_many_passes_and_levels_as_the_stage_counters_hold():
+    """A frame has ssaa^2 * (max_reflections + 1) stages and counters for 64 of them: 16 passes of four levels and one pass of
+    64 levels against the oracle, one stage more refused."""
+    fly, orc = make_pair("reflect_test", width=40, height=36)
+    assert_parity(compare(fly, orc, 40, 36, ssaa_level=4, max_reflections=3))
+    assert_parity(compare(fly, orc, 40, 36, ssaa_level=1, max_reflections=63))
+    assert_parity(compare(fly, orc, 40, 36, ssaa_level=8, max_reflections=0))
+    for kw, why in ((dict(ssaa_level=4, max_reflections=4), "exceeds 64"), (dict(ssaa_level=1, max_reflections=64), "exceeds 64"),
+                    (dict(ssaa_level=8, max_reflections=1), "exceeds 64"), (dict(ssaa_level=9, max_reflections=0), "outside 1..8")):
+        fly.set_params(**kw)
+        with pytest.raises(RuntimeError, match=why):
+            fly.render()
+
+
 def test_bounce_depth_sweep():
     fly, orc = make_pair("reflect_test", width=64, height=64)
     rays = []
