@@ -110,6 +110,36 @@ def test_equal_distance_later_face_wins():
     assert s.intersects([0.5, -0.5, 2], [0, 0, -1])[1] == 0
 
 
+def test_zero_over_zero_in_the_box_test_and_the_modes_that_settle_it():
+    # boundingBox::boxIntersection divides (side - origin) by the direction (boundingBox.h:258-271).  A ray with direction.x == 0
+    # that starts at x == 0 runs IN the plane of a box side at x == 0: 0 / 0.  With the reference's min / max a box that ENDS at
+    # that plane is turned away (tout becomes -inf) and one that STARTS there is taken (everything compares false).
+    mats = [dict(ka=(0, 0, 0), kd=(1, 1, 1), ks=(0, 0, 0), shininess=1.0)]
+    ends = np.array([[-1, -1, 0], [0, -1, 0], [0, 1, 0]], np.float32)    # x in [-1, 0]: the ray along x = 0 runs in its side
+    starts = np.array([[0, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32)   # x in [0, 1]
+    f = np.array([[0, 1, 2]], np.int32)
+    o, d = [0.0, 0.0, 2.0], [0.0, 0.0, -1.0]
+    for verts, as_reference in ((ends, False), (starts, True)):
+        s = OracleScene(arrays=(verts, None, f, np.zeros(1, np.int32), mats), normalize_model=False)
+        assert s.intersects(o, d)[0] == as_reference                      # the reference: depends on the side
+        assert s.intersects(o, d, reject_nan=1)[:2] == (True, 0)          # exact arithmetic: the ray touches the box; the edge x = 0 is hit
+        assert s.intersects(o, d, all_faces=1)[:2] == (True, 0)           # no box asked at all
+        assert s.intersects([0.25 if as_reference else -0.25, 0.0, 2.0], d)[:2] == (True, 0)  # an ordinary ray: every mode alike
+        # a frame flags the pixels whose rays met the 0 / 0 (here column W / 2 of an even-width image: its samples have n.x == 0)
+        r = s.render(8, 5)
+        assert r["nan_mask"][:, 4].any() and not r["nan_mask"][:, :4].any() and not r["nan_mask"][:, 5:].any()
+
+
+def test_all_faces_mode_changes_nothing_on_the_bundled_scenes():
+    # No box turns a ray away in this mode; on the reference's own scenes no box of the reference decides a pixel
+    for name, size in (("toy", (48, 40)), ("reflect_test", (64, 64)), ("NthTest", (40, 48))):
+        s = OracleScene(scene_path(name))
+        a = s.render(*size, max_reflections=2)
+        b = s.render(*size, max_reflections=2, all_faces=1)
+        assert np.array_equal(a["face_id"], b["face_id"]) and np.array_equal(a["rgb"].view(np.uint32), b["rgb"].view(np.uint32))
+        assert b["counters"].leaves_visited > a["counters"].leaves_visited
+
+
 def test_ppm_writer(tmp_path):
     rgb = np.zeros((1, 2, 3), np.float32)
     rgb[0, 0] = (0.4, 0.4, 0.4)
