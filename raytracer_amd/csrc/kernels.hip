@@ -1935,6 +1935,17 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
         ws.bin_feedback[0] = 0, ws.bin_feedback[1] = ws.bin_state->num_big; // [1]: faces too large for the face pass
         ws.bin_feedback[2] = from_keys ? 0 : 1, ws.bin_feedback[3] = 1;
     }
+    // A few listed faces (a ground plane under a mesh is two): their records and boxes once per workgroup into LDS, instead of
+    // three dependent fetches -- list entry, plane, corners -- per pixel and face in the loop below.
+    constexpr int kBigLds = 8;
+    __shared__ float4 s_big_rec[kBigLds][4];
+    __shared__ int4 s_big_box[kBigLds];
+    const bool big_in_lds = PRIMARY && from_keys && nbig_listed > 0 && nbig_listed <= kBigLds;
+    if (big_in_lds) {
+        if (tid < nbig_listed * 4) s_big_rec[tid >> 2][tid & 3] = sc.tris[(size_t)ws.big[tid >> 2].x * 4 + (size_t)(tid & 3)];
+        if (tid < nbig_listed) s_big_box[tid] = ws.big[tid];
+        __syncthreads();
+    }
     // the grid may be smaller than the work (it is sized from what earlier frames of the view needed): stride over it
     for (int first = block * (256 * kCompactSegments); first < total; first += nblocks * (256 * kCompactSegments)) {
     // A run of tiles none of which the face pass flagged holds no hit, and its pixels already hold the miss values: the
@@ -1992,14 +2003,25 @@ __device__ __forceinline__ void compact_body(const DeviceScene &sc, const FrameC
                     if (sc.num_spheres > 0 && spheres_hit(sc, o, d, fc.t_eps, ts) && ts < tbest) tbest = ts, tri = -1, best_rank = -1;
                     const int gy = global_row(fc, row);
                     for (int e = 0; e < nbig; ++e) {
-                        const int4 g = ws.big[e];
+                        // (LDS or memory by a branch the whole workgroup takes alike: one pointer chosen between the two
+                        // would turn every fetch into a flat access)
+                        int4 g;
+                        float4 pn;
+                        if (big_in_lds)
+                            g = s_big_box[e], pn = s_big_rec[e][0];
+                        else
+                            g = ws.big[e];
                         if (x < (g.y & 0xffff) || x > (g.z & 0xffff) || gy < (g.y >> 16) || gy > (g.z >> 16)) continue;
                         const float4 *rec = sc.tris + (size_t)g.x * 4;
-                        const float4 pn = rec[0];
+                        if (!big_in_lds) pn = rec[0];
                         const V3 n = mk(pn.x, pn.y, pn.z);
                         const float t = (pn.w - dot(o, n)) / dot(d, n);
                         if (!(t >= fc.t_eps && t <= tbest)) continue; // also rejects NaN (see file header)
-                        const float4 r0 = rec[1], r1 = rec[2], r2 = rec[3];
+                        float4 r0, r1, r2;
+                        if (big_in_lds)
+                            r0 = s_big_rec[e][1], r1 = s_big_rec[e][2], r2 = s_big_rec[e][3];
+                        else
+                            r0 = rec[1], r1 = rec[2], r2 = rec[3];
                         const int rank = __float_as_int(r1.w);
                         if (t == tbest && rank < best_rank) continue; // equal distance: the later face wins (:760)
                         const V3 v0 = mk(r0.x, r0.y, r0.z), v1 = mk(r1.x, r1.y, r1.z), v2 = mk(r2.x, r2.y, r2.z);
