@@ -916,6 +916,7 @@ int enqueue_frame(rtamd_scene *s, FrameSlot &fs, const FrameShape &shape, const 
     ws_frame.bin_max_list = s->bin_always ? 0x7fffffff : kMaxAverageBinList;
     ws_frame.num_bins = bins_x * bins_y;
     ws_frame.bins_expected = (bins_ok || faces_ok) && bins_kept_before;
+    ws_frame.listed_faces_expected = s->ds.num_spheres > 0 || (verdict && fs.view_key == view_key && verdict[3] != 0 && verdict[1] > 0);
     static const int forced_waves = getenv("RTAMD_FULL_WAVES") ? atoi(getenv("RTAMD_FULL_WAVES")) : -1; // experiment hook
     ws_frame.full_waves = forced_waves >= 0 ? forced_waves : s->num_slots > 1; // several caller streams: frames overlap
 

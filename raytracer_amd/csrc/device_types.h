@@ -164,6 +164,9 @@ struct Workspace {
     // The binning pass of the previous frame of this view kept its bins: the tree walk behind the bins, which only
     // runs when a pass turns them down, gets a small grid (it strides over the pixels), cheap to launch and to drain.
     int32_t bins_expected;
+    // Earlier frames of this view had faces in the list that the compaction tests pixel by pixel (or the scene has spheres): a hint
+    // that only picks between two equivalent forms of that kernel.
+    int32_t listed_faces_expected;
 };
 
 } // namespace rtamd
