@@ -38,7 +38,8 @@ for seed in range(first, first + count):
     lights = [tuple(rng.uniform(-2.0, 2.0, 3).tolist()) for _ in range(1 + seed % 2)]
     if seed % 5 == 0:
         lights.append((0.0, 1.5, 0.0))  # a light on an axis
-    fly, orc = make_pair(arrays=arrays, lights=lights, soft_points=seed % 3, normalize_model=False, width=W, height=H)
+    spheres = [tuple(rng.uniform(-0.6, 0.6, 3).tolist()) + (float(rng.uniform(0.05, 0.3)),) for _ in range(int(rng.integers(1, 4)))] if seed % 7 == 3 else ()
+    fly, orc = make_pair(arrays=arrays, lights=lights, soft_points=seed % 3, normalize_model=False, width=W, height=H, spheres=spheres)
     r = compare(fly, orc, W, H, all_faces=True, max_reflections=2, ssaa_level=ssaa)
     ok = (r["face_mismatch_pixels_all_faces"] == 0 and r["bad_pixels_all_faces"] == 0 and r["rays_gpu"] == r["rays_oracle_all_faces"]
           and r["face_mismatch_pixels_where_boxes_agree"] == 0 and r["bad_pixels_where_boxes_agree"] == 0)
